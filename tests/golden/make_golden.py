@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the REAL reference (oracle/_ref, built from /root/reference).
+
+Run in the build container only:   python tests/golden/make_golden.py
+The fixtures it writes are data (inputs + the reference's outputs); they are committed so
+the GPU box -- which has no /root/reference -- can check against them.
+
+  data/            the reference's bundled example data sets (inputs)
+  cli/*.cod        codebooks written by the reference's own tools ("%g" text)
+  cli/expected.json  what the tools printed (qerror, accuracy) + md5 of each .cod
+  traces/*.npz     in-memory fp32 results of som_training / lvq*_training driven through
+                   oracle/ref_harness.c, with the (index, diff) of every winner call
+"""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import RefHarness, build, ref_tool  # noqa: E402
+from som_lvq_pak_amd import textio  # noqa: E402
+
+REF_SRC = "/root/reference"
+DATA = os.path.join(HERE, "data")
+CLI = os.path.join(HERE, "cli")
+TR = os.path.join(HERE, "traces")
+
+
+def run(tool, *args):
+    cmd = [ref_tool(tool)] + [str(a) for a in args] + ["-v", "0"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=CLI)
+    if p.returncode != 0:
+        raise RuntimeError("%s failed: %s" % (cmd, p.stderr))
+    return p.stdout
+
+
+def md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+def synth(seed, n, d, k=6, spread=4.0):
+    """Seeded Gaussian mixture (legacy RandomState: stable across numpy versions)."""
+    rs = np.random.RandomState(seed)
+    centres = (spread * rs.standard_normal((k, d))).astype(np.float32)
+    which = rs.randint(0, k, size=n)
+    x = centres[which] + rs.standard_normal((n, d)).astype(np.float32)
+    return x.astype(np.float32), which.astype(np.int32) + 1
+
+
+def main():
+    build()
+    for p in (DATA, CLI, TR):
+        os.makedirs(p, exist_ok=True)
+    for f in ("ex.dat", "ex_fts.dat", "ex1.dat", "ex2.dat"):
+        shutil.copyfile(os.path.join(REF_SRC, f), os.path.join(DATA, f))
+        os.chmod(os.path.join(DATA, f), 0o644)
+    d = lambda f: os.path.join(DATA, f)  # noqa: E731
+    exp = {"som": {}, "lvq": {}}
+
+    # ---------------- SOM chains through the reference's own CLI ----------------
+    for topol in ("hexa", "rect"):
+        for neigh in ("bubble", "gaussian"):
+            tag = "%s_%s" % (topol, neigh)
+            init = "som_init_%s.cod" % tag
+            run("randinit", "-din", d("ex.dat"), "-cout", init, "-xdim", 12, "-ydim", 8,
+                "-topol", topol, "-neigh", neigh, "-rand", 123)
+            out = "som_%s.cod" % tag
+            run("vsom", "-din", d("ex.dat"), "-cin", init, "-cout", out, "-rlen", 5000,
+                "-alpha", 0.05, "-radius", 10)
+            q = run("qerror", "-din", d("ex.dat"), "-cin", out)
+            exp["som"][tag] = {"init": init, "out": out, "rlen": 5000, "alpha": 0.05, "radius": 10,
+                               "qerror_stdout": q, "md5": md5(os.path.join(CLI, out))}
+    init = "som_init_hexa_bubble.cod"
+    run("vsom", "-din", d("ex.dat"), "-cin", init, "-cout", "som_invt.cod", "-rlen", 5000,
+        "-alpha", 0.05, "-radius", 10, "-alpha_type", "inverse_t")
+    exp["som"]["inverse_t"] = {"init": init, "out": "som_invt.cod",
+                               "qerror_stdout": run("qerror", "-din", d("ex.dat"), "-cin", "som_invt.cod"),
+                               "md5": md5(os.path.join(CLI, "som_invt.cod"))}
+    run("vsom", "-din", d("ex.dat"), "-cin", init, "-cout", "som_rand7.cod", "-rlen", 5000,
+        "-alpha", 0.05, "-radius", 10, "-rand", 7)
+    exp["som"]["rand7"] = {"init": init, "out": "som_rand7.cod",
+                           "qerror_stdout": run("qerror", "-din", d("ex.dat"), "-cin", "som_rand7.cod"),
+                           "md5": md5(os.path.join(CLI, "som_rand7.cod"))}
+    exp["som"]["qerror2_r2"] = run("qerror", "-din", d("ex.dat"), "-cin", "som_hexa_bubble.cod",
+                                   "-qetype", 1, "-radius", 2)
+    # the reference Makefile's `somexample` (Makefile:195-205)
+    shutil.copyfile(os.path.join(CLI, init), os.path.join(CLI, "somexample.cod"))
+    run("vsom", "-din", d("ex.dat"), "-cin", "somexample.cod", "-cout", "somexample.cod",
+        "-rlen", 1000, "-alpha", 0.05, "-radius", 10)
+    run("vsom", "-din", d("ex.dat"), "-cin", "somexample.cod", "-cout", "somexample.cod",
+        "-rlen", 10000, "-alpha", 0.02, "-radius", 3)
+    exp["som"]["somexample"] = {"qerror_stdout": run("qerror", "-din", d("ex.dat"), "-cin", "somexample.cod"),
+                                "md5": md5(os.path.join(CLI, "somexample.cod"))}
+    shutil.copyfile(os.path.join(CLI, "somexample.cod"), os.path.join(CLI, "somexample_vcal.cod"))
+    run("vcal", "-din", d("ex_fts.dat"), "-cin", "somexample.cod", "-cout", "somexample_vcal.cod")
+    exp["som"]["somexample_vcal_md5"] = md5(os.path.join(CLI, "somexample_vcal.cod"))
+
+    # ---------------- LVQ chains ----------------
+    run("eveninit", "-din", d("ex1.dat"), "-cout", "lvq_init.cod", "-noc", 200)
+    exp["lvq"]["init_md5"] = md5(os.path.join(CLI, "lvq_init.cod"))
+    runs = {
+        "lvq1_10000": ("lvq1", ["-rlen", 10000, "-alpha", 0.05]),
+        "lvq1": ("lvq1", ["-rlen", 5000, "-alpha", 0.05]),
+        "lvq2": ("lvq2", ["-rlen", 5000, "-alpha", 0.05, "-win", 0.3]),
+        "lvq3": ("lvq3", ["-rlen", 5000, "-alpha", 0.05, "-win", 0.3, "-epsilon", 0.1]),
+        "olvq1": ("olvq1", ["-rlen", 5000, "-alpha", 0.05]),
+        "olvq1_default": ("olvq1", ["-rlen", 5000]),
+    }
+    for tag, (tool, args) in runs.items():
+        out = "lvq_%s.cod" % tag
+        run(tool, "-din", d("ex1.dat"), "-cin", "lvq_init.cod", "-cout", out, *args)
+        acc = run("accuracy", "-din", d("ex2.dat"), "-cin", out)
+        exp["lvq"][tag] = {"tool": tool, "args": [str(a) for a in args], "out": out,
+                           "accuracy_stdout": acc, "md5": md5(os.path.join(CLI, out))}
+    json.dump(exp, open(os.path.join(CLI, "expected.json"), "w"), indent=1, sort_keys=True)
+
+    # ---------------- in-memory traces through the harness ----------------
+    ref = RefHarness()
+    ex, _ = textio.read_entries(d("ex.dat"))
+    for topol in ("hexa", "rect"):
+        for neigh in ("bubble", "gaussian"):
+            tag = "%s_%s" % (topol, neigh)
+            ini, _ = textio.read_entries(os.path.join(CLI, "som_init_%s.cod" % tag))
+            for at, atname in ((1, "linear"), (2, "inverse_t")):
+                if at == 2 and tag != "hexa_bubble":
+                    continue
+                codes, ti, td = ref.som_train(ini.points, 12, 8, ini.topol, ini.neigh, ex.points,
+                                              5000, 0.05, 10.0, alpha_type=at)
+                q, qi, qd = ref.find_qerror(codes, ex.points)
+                np.savez_compressed(os.path.join(TR, "som_ex_%s_%s.npz" % (tag, atname)),
+                                    codes=codes, trace_index=ti.astype(np.int32), trace_diff=td,
+                                    qerror_sum=np.float32(q), q_index=qi.astype(np.int32), q_diff=qd,
+                                    params=np.array([12, 8, ini.topol, ini.neigh, 5000, at]),
+                                    alpha=np.float32(0.05), radius=np.float32(10.0))
+    # qerror -qetype 1
+    hb, _ = textio.read_entries(os.path.join(CLI, "som_hexa_bubble.cod"))
+    hg, _ = textio.read_entries(os.path.join(CLI, "som_hexa_gaussian.cod"))
+    np.savez_compressed(os.path.join(TR, "som_qerror2.npz"),
+                        bubble_r2=np.float32(ref.find_qerror2(hb.points, 12, 3, 1, ex.points, 2.0)),
+                        gaussian_r2=np.float32(ref.find_qerror2(hg.points, 12, 3, 2, ex.points, 2.0)))
+
+    # synthetic: masks + weights + fixed points (the bundled data has none of them)
+    x, _ = synth(11, 300, 6)
+    rs = np.random.RandomState(12)
+    mask = (rs.rand(300, 6) < 0.15).astype(np.uint8)
+    mask[7, :] = 1                       # a fully masked sample -> skipped (som_rout.c:635-640)
+    weight = rs.randint(0, 4, size=300).astype(np.int16)
+    fixed = np.full((300, 2), -1, dtype=np.int16)
+    for r in rs.choice(300, 20, replace=False):
+        fixed[r] = (rs.randint(0, 7), rs.randint(0, 5))
+    ini = ref.randinit(x, 7, 5, 99)
+    for neigh in (1, 2):
+        codes, ti, td = ref.som_train(ini, 7, 5, 3, neigh, x, 1500, 0.08, 4.0, weight=weight,
+                                      fixed_xy=fixed, mask=mask, fixed_on=1, weights_on=1)
+        np.savez_compressed(os.path.join(TR, "som_masked_%d.npz" % neigh), init=ini, codes=codes,
+                            trace_index=ti.astype(np.int32), trace_diff=td, mask=mask,
+                            weight=weight, fixed=fixed, x=x,
+                            params=np.array([7, 5, 3, neigh, 1500, 1]),
+                            alpha=np.float32(0.08), radius=np.float32(4.0))
+
+    # synthetic mid-size map: only hashes + index trace (data regenerated from the seed)
+    x, _ = synth(21, 4000, 48, k=8)
+    ini = ref.randinit(x, 24, 16, 5)
+    for topol, neigh in ((3, 1), (4, 2)):
+        codes, ti, td = ref.som_train(ini, 24, 16, topol, neigh, x, 6000, 0.05, 8.0)
+        q, _, _ = ref.find_qerror(codes, x)
+        np.savez_compressed(os.path.join(TR, "som_synth_%d_%d.npz" % (topol, neigh)),
+                            init_sha=hashlib.sha256(ini.tobytes()).hexdigest(),
+                            codes_sha=hashlib.sha256(codes.tobytes()).hexdigest(),
+                            trace_index=ti.astype(np.int32),
+                            trace_diff_sha=hashlib.sha256(td.tobytes()).hexdigest(),
+                            qerror_sum=np.float32(q),
+                            params=np.array([24, 16, topol, neigh, 6000, 1, 21, 4000, 48, 8, 5]),
+                            alpha=np.float32(0.05), radius=np.float32(8.0))
+
+    # LVQ on ex1.dat
+    tab = textio.LabelTable()
+    e1, _ = textio.read_entries(d("ex1.dat"), tab)
+    ci, _ = textio.read_entries(os.path.join(CLI, "lvq_init.cod"), tab)
+    e2, _ = textio.read_entries(d("ex2.dat"), tab)
+    for tag, kind, kw in (("lvq1", 1, {}), ("olvq1", 2, {}), ("lvq2", 3, {"winlen": 0.3}),
+                          ("lvq3", 4, {"winlen": 0.3, "epsilon": 0.1}),
+                          ("lvq1_invt", 1, {"alpha_type": 2})):
+        codes, tal, ti, td = ref.lvq_train(kind, ci.points, ci.first_label, e1.points,
+                                           e1.first_label, 5000, 0.05, **kw)
+        wi, _, _ = ref.winners(codes, e2.points)
+        acc = int((ci.first_label[wi[:, 0]] == e2.first_label).sum())
+        extra = {}
+        if tal is not None:
+            extra["lra"] = np.array(tal)
+        np.savez_compressed(os.path.join(TR, "lvq_ex1_%s.npz" % tag), codes=codes,
+                            trace_index=ti.astype(np.int32), trace_diff=td,
+                            correct_on_ex2=np.int64(acc), kind=np.int64(kind), **extra)
+    # k-NN scans (find_winner_knn tie order etc.): duplicate rows force exact ties
+    cb = np.concatenate([ci.points[:40], ci.points[:40]], axis=0)
+    for knn in (1, 2, 5):
+        wi, wd, _ = ref.winners(cb, e2.points[:300], knn=knn, use_knn_fn=True)
+        np.savez_compressed(os.path.join(TR, "knn_ties_%d.npz" % knn), index=wi.astype(np.int32),
+                            diff=wd)
+    wi, wd, _ = ref.winners(cb, e2.points[:300], knn=1, use_knn_fn=False)
+    np.savez_compressed(os.path.join(TR, "euc_ties.npz"), index=wi.astype(np.int32), diff=wd)
+
+    # scalars: schedules, lattice distances, RNG, shuffle
+    its = np.array([0, 1, 2, 17, 999, 4999, 5000, 123456, 9999999, 16777217, 99999999], dtype=np.int64)
+    lens = np.array([1, 5000, 10000, 10000000, 100000000], dtype=np.int64)
+    alphas = np.array([[ref.alpha(t, int(i), int(l), 0.05) if i <= l else 0.0 for i in its]
+                       for t in (1, 2) for l in lens], dtype=np.float32)
+    md = np.array([[ref.mapdist(tp, bx, by, tx, ty) for tp in (3, 4)]
+                   for bx in range(0, 9, 2) for by in range(0, 7) for tx in range(0, 9, 3)
+                   for ty in range(0, 7)], dtype=np.float32)
+    np.savez_compressed(os.path.join(TR, "scalars.npz"), its=its, lens=lens, alphas=alphas,
+                        mapdist=md, rand123=ref.rand_seq(123, 200), perm7=ref.shuffle_perm(3840, 7),
+                        perm_small=ref.shuffle_perm(10, 3), randinit_ex=ref.randinit(ex.points, 12, 8, 123))
+    print("golden fixtures written under", HERE)
+
+
+if __name__ == "__main__":
+    main()
