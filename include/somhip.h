@@ -1,0 +1,163 @@
+/* somhip.h -- C ABI of the MI355X (gfx950) SOM/LVQ training engine.
+ *
+ * This is the drop-in boundary for the hot path of SOM_PAK/LVQ_PAK 3.2
+ * (hynde/som_lvq_pak): best-matching-unit search + codebook update inside the
+ * vsom / lvqtrain epoch loops, and the read-only winner scans of qerror /
+ * accuracy / vcal.  Plain C: opaque handles, plain pointers and sizes, int status
+ * (0 = ok, nonzero = error; text via somhip_last_error()).  Nothing here aborts; a
+ * failing call leaves a message and returns nonzero, the way the reference's
+ * training functions return NULL and print to stderr (som_rout.c:576-596).
+ *
+ * One host thread per engine (the reference is single-threaded and not re-entrant,
+ * SURVEY.md 8b); one engine per process per GPU.
+ *
+ * Each entry point cites the reference interface it replaces (file:line in
+ * hynde/som_lvq_pak).  INTEGRATION.md shows the reference-side binding.
+ */
+#ifndef SOMHIP_H
+#define SOMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOMHIP_VERSION 1
+
+/* ids equal to the reference's (lvq_pak.h:209-224) */
+enum { SOMHIP_TOPOL_LVQ = 2, SOMHIP_TOPOL_HEXA = 3, SOMHIP_TOPOL_RECT = 4 };
+enum { SOMHIP_NEIGH_BUBBLE = 1, SOMHIP_NEIGH_GAUSSIAN = 2 };
+enum { SOMHIP_ALPHA_LINEAR = 1, SOMHIP_ALPHA_INVERSE_T = 2 };
+enum { SOMHIP_LVQ1 = 1, SOMHIP_OLVQ1 = 2, SOMHIP_LVQ2 = 3, SOMHIP_LVQ3 = 4 };
+
+/* winner tie rules: FIRST = find_winner_euc (lowest index among equal distances,
+ * lvq_pak.c:79); KNN = find_winner_knn with knn >= 2 (later row first, lvq_pak.c:197) */
+enum { SOMHIP_TIE_FIRST = 0, SOMHIP_TIE_KNN = 1 };
+
+typedef struct somhip_engine somhip_engine;
+typedef struct somhip_codebook somhip_codebook;   /* replaces the `codes` entries list, lvq_pak.h:89-113 */
+typedef struct somhip_dataset somhip_dataset;     /* replaces the `data` entries list (one -buffer worth) */
+
+const char *somhip_last_error(void);
+int somhip_version(void);
+
+/* ---- engine ---- */
+int  somhip_engine_create(int device, somhip_engine **out);
+void somhip_engine_destroy(somhip_engine *e);
+/* the HIP stream all work of this engine is enqueued on (a hipStream_t) */
+void *somhip_engine_stream(somhip_engine *e);
+int  somhip_engine_sync(somhip_engine *e);
+
+/* ---- codebook mirror -------------------------------------------------------
+ * rows: host, row-major [n_rows][dim] fp32, row k = list position k of the
+ * reference's codebook (datafile.c:781,836) = map unit (k % xdim, k / xdim)
+ * (som_rout.c:641-642).  labels: first label of each row (labels.h:44) or NULL.
+ * For a row-sharded codebook (multi-GPU) this process holds global rows
+ * [row_offset, row_offset + n_rows) of n_global; single GPU: row_offset 0,
+ * n_global == n_rows. */
+int  somhip_codebook_create(somhip_engine *e, const float *rows, const int32_t *labels,
+                            int64_t n_rows, int dim, int topol, int neigh, int xdim, int ydim,
+                            int64_t row_offset, int64_t n_global, somhip_codebook **out);
+/* device -> host gather of the rows (what save_entries / save_snapshot need,
+ * datafile.c:353, lvq_pak.c:665) */
+int  somhip_codebook_download(somhip_codebook *cb, float *rows);
+int  somhip_codebook_upload(somhip_codebook *cb, const float *rows);
+void somhip_codebook_destroy(somhip_codebook *cb);
+
+/* ---- data mirror -----------------------------------------------------------
+ * rows row-major [n_rows][dim]; optional per-row arrays (NULL = absent):
+ *   mask    [n_rows][dim] nonzero = component ignored (data_entry.mask, lvq_pak.h:84)
+ *   labels  first label per row                      (labels.h:44)
+ *   weight  data_entry.weight                        (lvq_pak.h:81)
+ *   fixed_xy [n_rows][2], -1 = none                  (struct fixpoint, lvq_pak.h:65) */
+int  somhip_dataset_create(somhip_engine *e, const float *rows, int64_t n_rows, int dim,
+                           const uint8_t *mask, const int32_t *labels, const int16_t *weight,
+                           const int16_t *fixed_xy, somhip_dataset **out);
+/* same, but `dev_rows` already lives in this GPU's memory (row-major fp32) and is
+ * used in place, not copied (bench / streaming ingest) */
+int  somhip_dataset_wrap_device(somhip_engine *e, const float *dev_rows, int64_t n_rows, int dim,
+                                somhip_dataset **out);
+void somhip_dataset_destroy(somhip_dataset *ds);
+
+/* ---- winner scans: WINNER_FUNCTION over a run of samples (lvq_pak.h:146) -----
+ * find_winner_euc (lvq_pak.c:41) when tie == SOMHIP_TIE_FIRST and knn == 1,
+ * find_winner_knn (lvq_pak.c:152) when tie == SOMHIP_TIE_KNN (1 <= knn <= 8).
+ * Samples are data rows [first, first+count).  Outputs are host arrays
+ * [count][knn]: index = global row (or -1: nothing beat FLT_MAX), diff = SQUARED
+ * distance exactly as the reference's fp32 left-to-right sum gives it; ret[i] = the
+ * function's return value (knn, or 0 = every component masked). ret may be NULL. */
+int  somhip_find_winners(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
+                         int knn, int tie, int32_t *index, float *diff, int32_t *ret);
+
+/* ---- som_training (som_rout.c:556-671) --------------------------------------
+ * Runs iterations [start_iter, start_iter+count) of a schedule of `length`
+ * iterations; iteration le uses data row (data_first + (le - start_iter)) % n_rows.
+ * batch == 1: the reference's strictly online algorithm, bit-exact.
+ * batch  > 1: mini-batch schedule -- the winners of each run of `batch` iterations
+ *             are found against the codebook as it stood before the run, then the
+ *             neighbourhood updates are applied in iteration order (exact oracle:
+ *             orc_som_training(batch) in oracle/).
+ * trace_index/trace_diff (host, [count], may be NULL): winner of every iteration;
+ * -2 = skipped (sample fully masked), -3 = fixed-point sample (no search). */
+typedef struct somhip_som_params {
+  int64_t length;        /* teach_params.length  (lvq_pak.h:198) */
+  float   alpha;         /* teach_params.alpha   (lvq_pak.h:197) */
+  float   radius;        /* teach_params.radius  (lvq_pak.h:196) */
+  int32_t alpha_type;    /* teach_params.alpha_type (lvq_pak.h:189) */
+  int32_t use_fixed;     /* use_fixed(-1)   (lvq_pak.c:508) */
+  int32_t use_weights;   /* use_weights(-1) (lvq_pak.c:519) */
+  int64_t batch;
+  int64_t start_iter, count, data_first;
+} somhip_som_params;
+int  somhip_som_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
+                      int32_t *trace_index, float *trace_diff);
+
+/* ---- lvq1/olvq1/lvq2/lvq3_training (lvq_rout.c:498,584,702,808) --------------
+ * kind = SOMHIP_LVQ1..LVQ3.  talpha (host, [n_rows], in/out) = OLVQ1's per-code
+ * rates, initialised by the caller the way lvq_rout.c:614-627 does; `alpha` is also
+ * OLVQ1's clamp (:671).  Online (batch 1) only in this version.  The trace has knn
+ * entries per iteration (knn = 2 for LVQ2/LVQ3, else 1). */
+typedef struct somhip_lvq_params {
+  int32_t kind;
+  int64_t length;
+  float   alpha;
+  int32_t alpha_type;
+  float   winlen;        /* -win     (lvq_rout.c:702) */
+  float   epsilon;       /* -epsilon (lvq_rout.c:808) */
+  int64_t start_iter, count, data_first;
+} somhip_lvq_params;
+int  somhip_lvq_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_lvq_params *p,
+                      float *talpha, int32_t *trace_index, float *trace_diff);
+
+/* ---- two-phase mini-batch primitives (what somhip_som_train(batch>1) is made of;
+ * exposed so a multi-GPU host can put its collective between them) -------------
+ * keys: DEVICE array [count] of uint64 = (fp32 bits of squared distance << 32) |
+ * global row index.  All distances are >= 0, so unsigned order == (distance, index)
+ * order and an element-wise MIN across shards is exactly find_winner_euc over the
+ * whole codebook, lowest index winning ties (lvq_pak.c:79). */
+int  somhip_batch_winner_keys(somhip_codebook *cb, somhip_dataset *ds, int64_t first,
+                              int64_t count, uint64_t *dev_keys);
+int  somhip_som_batch_update(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
+                             int64_t batch_start_iter, int64_t count, int64_t data_first,
+                             const uint64_t *dev_keys);
+/* device scratch helpers for hosts without their own allocator */
+int  somhip_device_alloc(somhip_engine *e, int64_t bytes, void **dev_ptr);
+int  somhip_device_free(somhip_engine *e, void *dev_ptr);
+int  somhip_copy_to_host(somhip_engine *e, void *host_dst, const void *dev_src, int64_t bytes);
+int  somhip_copy_to_device(somhip_engine *e, void *dev_dst, const void *host_src, int64_t bytes);
+
+/* ---- instrumentation ---------------------------------------------------------
+ * Per-kernel launch statistics measured with HIP events on the engine's stream
+ * (used by bench.py for the roofline line).  name = one of the kernel names
+ * returned by somhip_kernel_name(i), i in [0, somhip_kernel_count()). */
+int  somhip_timing_enable(somhip_engine *e, int on);
+int  somhip_timing_reset(somhip_engine *e);
+int  somhip_kernel_count(void);
+const char *somhip_kernel_name(int i);
+int  somhip_timing_get(somhip_engine *e, int kernel, int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOMHIP_H */

@@ -1,0 +1,708 @@
+// kernels.hpp -- gfx950 (MI355X, CDNA4) device code of the SOM/LVQ engine.
+//
+// Numerics contract (bit-exact with the reference's CPU code): distances are the
+// left-to-right fp32 sum of (c_i - x_i)^2 with a separate rounding after the
+// subtract, the multiply and the add (reference lvq_pak.c:70-71); updates are
+// c = c + alpha*(x - c) with three roundings (lvq_pak.c:348-349).  This file is
+// compiled with -ffp-contract=off and must contain no fma/mac in those chains
+// (checked on the ISA by tests/test_build.py).
+//
+// Data layout in HBM ("row-group tiles"): the codebook is stored as
+//     tile[g][q][lane][4]    g = row / 64, lane = row % 64, q = dim / 4
+// i.e. for every group of 64 consecutive code rows and every chunk of 4 dims, the
+// 64 float4 of that chunk are contiguous (1 KiB).  One lane of a wavefront owns one
+// code row, walks its dims in order (which the sequential-sum contract needs) and
+// every wave-level load/store is one fully coalesced 1 KiB access.  Rows >= n and
+// dims >= d are zero padding (adding +0.0f to a sum of squares is exact).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace somhip {
+
+constexpr int WAVE = 64;
+constexpr uint64_t KEY_NONE = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint32_t FLT_MAX_BITS = 0x7F7FFFFFu;
+
+struct CbView {
+  float *tiles;         // [ngroups][d4][64][4]
+  int64_t n;            // local rows
+  int64_t ngroups;      // ceil(n / 64)
+  int d, d4;
+  int64_t row_offset;   // global index of local row 0
+  int xdim;             // map width (global)
+  int topol, neigh;
+};
+
+__device__ __forceinline__ const float4 *tile_ptr(const CbView &cb, int64_t g, int q, int lane) {
+  return reinterpret_cast<const float4 *>(cb.tiles) + ((g * cb.d4 + q) * WAVE + lane);
+}
+__device__ __forceinline__ float4 *tile_ptr_w(const CbView &cb, int64_t g, int q, int lane) {
+  return reinterpret_cast<float4 *>(cb.tiles) + ((g * cb.d4 + q) * WAVE + lane);
+}
+
+// ---- exact arithmetic helpers (no contraction: see file header) ----
+__device__ __forceinline__ float sq_acc(float acc, float c, float x) {
+  float t = c - x;
+  float p = t * t;
+  return acc + p;
+}
+__device__ __forceinline__ float adapt1(float c, float x, float a) {
+  float t = x - c;
+  float s = a * t;
+  return c + s;
+}
+__device__ __forceinline__ float4 adapt4(float4 c, float4 x, float a) {
+  return make_float4(adapt1(c.x, x.x, a), adapt1(c.y, x.y, a), adapt1(c.z, x.z, a),
+                     adapt1(c.w, x.w, a));
+}
+
+// key = (distance bits << 32) | tag ; distances are >= 0 so unsigned order = value order
+__device__ __forceinline__ uint64_t make_key(float dist, uint32_t tag) {
+  return (static_cast<uint64_t>(__float_as_uint(dist)) << 32) | tag;
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    uint64_t o = __shfl_xor(v, off, WAVE);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// ---- lattice distance, squared, exactly as the reference forms it before its sqrt
+// hexa_dist som_rout.c:438-451, rect_dist :461-464.  The sqrt itself is folded into
+// a host-computed threshold (bubble) or taken in double (gaussian).
+__device__ __forceinline__ float lattice_sq(int topol, int bx, int by, int tx, int ty) {
+  float dx = static_cast<float>(bx - tx);
+  float dy = static_cast<float>(by - ty);
+  if (topol == 4 /*rect*/) {
+    float r = dx * dx;
+    float r2 = dy * dy;
+    return r + r2;
+  }
+  if (((by - ty) % 2) != 0) {
+    dx = ((by % 2) == 0) ? static_cast<float>(static_cast<double>(dx) - 0.5)
+                         : static_cast<float>(static_cast<double>(dx) + 0.5);
+  }
+  float r = dx * dx;
+  double t = 0.75 * static_cast<double>(dy);
+  t = t * static_cast<double>(dy);
+  return static_cast<float>(static_cast<double>(r) + t);
+}
+
+// gaussian_adapt's factor, som_rout.c:539-542
+__device__ __forceinline__ float gaussian_alpha(float lat_sq, float radius, float alpha) {
+  float dd = static_cast<float>(sqrt(static_cast<double>(lat_sq)));
+  float neg = -dd * dd;
+  double den = 2.0 * static_cast<double>(radius);
+  den = den * static_cast<double>(radius);
+  float h = static_cast<float>(exp(static_cast<double>(neg) / den));
+  return alpha * h;
+}
+
+// per-iteration scalars, computed on the host with the reference's own expressions
+struct StepScalars {
+  float alpha;     // talp after schedule (+ weights), som_rout.c:617-624
+  float thresh;    // bubble: largest lattice_sq value still inside the radius; gaussian: trad
+  int32_t fixed;   // >= 0: unit index from the sample's fixed point (som_rout.c:628-632)
+  int32_t skip;    // 1: every component masked -> no search, no update (som_rout.c:635-640)
+};
+
+// =====================================================================================
+// K-layout: row-major host rows <-> row-group tiles
+// =====================================================================================
+__global__ void k_rows_to_tiles(const float *__restrict__ rows, CbView cb) {
+  int64_t g = blockIdx.x;
+  int lane = threadIdx.x & 63;
+  int64_t row = g * WAVE + lane;
+  for (int q = threadIdx.x >> 6; q < cb.d4; q += blockDim.x >> 6) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int i = q * 4 + j;
+      v[j] = (row < cb.n && i < cb.d) ? rows[row * cb.d + i] : 0.0f;
+    }
+    *tile_ptr_w(cb, g, q, lane) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+__global__ void k_tiles_to_rows(float *__restrict__ rows, CbView cb) {
+  int64_t g = blockIdx.x;
+  int lane = threadIdx.x & 63;
+  int64_t row = g * WAVE + lane;
+  if (row >= cb.n) return;
+  for (int q = threadIdx.x >> 6; q < cb.d4; q += blockDim.x >> 6) {
+    float4 v = *tile_ptr(cb, g, q, lane);
+    float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int i = q * 4 + j;
+      if (i < cb.d) rows[row * cb.d + i] = a[j];
+    }
+  }
+}
+
+// =====================================================================================
+// K-pack: a run of samples, row-major [count][d] (wrapping inside the data set) ->
+// sample tiles xt[sb][q][S][4]: for every block of S samples and every chunk of 4
+// dims the S float4 are contiguous, so the scan kernel reads a sample tile with
+// wave-uniform (scalar) loads.  Samples >= count and dims >= d are zero.
+// =====================================================================================
+template <int S>
+__global__ void k_pack_samples(const float *__restrict__ rows, int64_t n_rows, int d, int d4,
+                               int64_t first, int64_t count, float4 *__restrict__ xt) {
+  int64_t sb = blockIdx.x;
+  for (int e = threadIdx.x; e < d4 * S; e += blockDim.x) {
+    int q = e / S, s = e % S;
+    int64_t smp = sb * S + s;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (smp < count) {
+      int64_t r = (first + smp) % n_rows;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int i = q * 4 + j;
+        if (i < d) v[j] = rows[r * d + i];
+      }
+    }
+    xt[(sb * d4 + q) * S + s] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// =====================================================================================
+// K1: exact winner scan of a tile of S samples against 64*R code rows per wave.
+//
+// find_winner_euc (lvq_pak.c:41-94) / find_winner_knn (lvq_pak.c:152-221) for a whole
+// run of samples at once.  One lane = one code row (R rows when R > 1), S running sums
+// per row kept in registers; every (row, sample) sum is formed in dim order with
+// separate sub/mul/add roundings, so each value equals the reference's bit for bit.
+// The reference's early exit (lvq_pak.c:72) is result-neutral and not reproduced.
+//
+// grid.x = sample tiles (fastest: consecutive workgroups share the code tile in L2 and
+// each XCD keeps seeing the same sample tiles), grid.y = code-row blocks of 4*R groups.
+//
+// TOPK == 1: the winner per sample is folded into keys[sample] with a 64-bit atomic
+//            min of (distance bits, tag); tag = global row (FIRST tie rule) or
+//            ~global row (KNN tie rule: later row first).
+// TOPK  > 1: every workgroup writes its TOPK best keys per sample to
+//            partial[sample][gridDim.y][TOPK]; k_merge_topk finishes.
+// =====================================================================================
+template <int S, int R, int TOPK>
+__global__ __launch_bounds__(256) void k_scan_exact(CbView cb, const float4 *__restrict__ xt,
+                                                    int64_t count, int tie_knn,
+                                                    uint64_t *__restrict__ keys,
+                                                    uint64_t *__restrict__ partial) {
+  __shared__ uint64_t red[4][S][TOPK];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t sb = blockIdx.x;
+  const int64_t g0 = (static_cast<int64_t>(blockIdx.y) * 4 + wave) * R;
+  const float4 *xtile = xt + sb * cb.d4 * S;
+
+  float acc[R][S];
+#pragma unroll
+  for (int r = 0; r < R; r++)
+#pragma unroll
+    for (int s = 0; s < S; s++) acc[r][s] = 0.0f;
+
+  if (g0 < cb.ngroups) {
+    for (int q = 0; q < cb.d4; q++) {
+      float4 c[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        int64_t g = g0 + r < cb.ngroups ? g0 + r : cb.ngroups - 1;
+        c[r] = *tile_ptr(cb, g, q, lane);
+      }
+#pragma unroll
+      for (int s = 0; s < S; s++) {
+        float4 x = xtile[q * S + s];          // wave-uniform address
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          float a = acc[r][s];
+          a = sq_acc(a, c[r].x, x.x);
+          a = sq_acc(a, c[r].y, x.y);
+          a = sq_acc(a, c[r].z, x.z);
+          a = sq_acc(a, c[r].w, x.w);
+          acc[r][s] = a;
+        }
+      }
+    }
+  }
+
+  // per-sample reduction over this wave's rows
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    uint64_t k[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int64_t row = (g0 + r) * WAVE + lane;
+      bool live = (g0 + r) < cb.ngroups && row < cb.n;
+      uint32_t grow = static_cast<uint32_t>(row + cb.row_offset);
+      k[r] = live ? make_key(acc[r][s], tie_knn ? ~grow : grow) : KEY_NONE;
+    }
+#pragma unroll
+    for (int t = 0; t < TOPK; t++) {
+      uint64_t mine = k[0];
+#pragma unroll
+      for (int r = 1; r < R; r++) mine = k[r] < mine ? k[r] : mine;
+      uint64_t best = wave_min_u64(mine);
+      if (TOPK > 1) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          if (k[r] == best) k[r] = KEY_NONE;   // keys are unique (tag = row)
+      }
+      if (lane == 0) red[wave][s][t] = best;
+    }
+  }
+  __syncthreads();
+  // merge the 4 waves: thread (s, t-th smallest)
+  for (int e = threadIdx.x; e < S; e += blockDim.x) {
+    int64_t smp = sb * S + e;
+    if (smp >= count) continue;
+    uint64_t cand[4 * TOPK];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int t = 0; t < TOPK; t++) cand[w * TOPK + t] = red[w][e][t];
+    if (TOPK == 1) {
+      uint64_t b = cand[0];
+#pragma unroll
+      for (int w = 1; w < 4; w++) b = cand[w] < b ? cand[w] : b;
+      atomicMin(reinterpret_cast<unsigned long long *>(keys + smp),
+                static_cast<unsigned long long>(b));
+    } else {
+      for (int t = 0; t < TOPK; t++) {
+        int arg = 0;
+        uint64_t b = cand[0];
+        for (int j = 1; j < 4 * TOPK; j++)
+          if (cand[j] < b) { b = cand[j]; arg = j; }
+        cand[arg] = KEY_NONE;
+        partial[(smp * gridDim.y + blockIdx.y) * TOPK + t] = b;
+      }
+    }
+  }
+}
+
+// merge partial[sample][nblk][K] -> keys_out[sample][K]; one wave per sample
+template <int K>
+__global__ void k_merge_topk(const uint64_t *__restrict__ partial, int nblk, int64_t count,
+                             uint64_t *__restrict__ keys_out) {
+  int64_t smp = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (smp >= count) return;
+  const uint64_t *p = partial + smp * nblk * K;
+  int total = nblk * K;
+  uint64_t prev = 0;
+  bool first = true;
+  for (int t = 0; t < K; t++) {
+    uint64_t mine = KEY_NONE;
+    for (int j = lane; j < total; j += WAVE) {
+      uint64_t v = p[j];
+      if ((first || v > prev) && v < mine) mine = v;   // keys are unique
+    }
+    uint64_t best = wave_min_u64(mine);
+    if (lane == 0) keys_out[smp * K + t] = best;
+    prev = best;
+    first = false;
+    if (best == KEY_NONE) { for (int u = t + 1; u < K; u++) if (lane == 0) keys_out[smp * K + u] = KEY_NONE; break; }
+  }
+}
+
+// =====================================================================================
+// K1m: masked variant, one sample per launch column (rare path: data with 'x'
+// components, lvq_pak.c:65-69).  mask is wave-uniform per component.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_scan_masked(CbView cb, const float *__restrict__ rows,
+                                                     const uint8_t *__restrict__ mask,
+                                                     int64_t n_rows, int64_t first, int64_t count,
+                                                     int tie_knn, uint64_t *__restrict__ keys) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t smp = blockIdx.y;
+  const int64_t r = (first + smp) % n_rows;
+  const float *x = rows + r * cb.d;
+  const uint8_t *m = mask + r * cb.d;
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  if (g >= cb.ngroups) return;
+  float acc = 0.0f;
+  for (int q = 0; q < cb.d4; q++) {
+    float4 c = *tile_ptr(cb, g, q, lane);
+    float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int i = q * 4 + j;
+      if (i < cb.d && m[i] == 0) acc = sq_acc(acc, cc[j], x[i]);
+    }
+  }
+  int64_t row = g * WAVE + lane;
+  uint32_t grow = static_cast<uint32_t>(row + cb.row_offset);
+  uint64_t k = row < cb.n ? make_key(acc, tie_knn ? ~grow : grow) : KEY_NONE;
+  k = wave_min_u64(k);
+  if (lane == 0)
+    atomicMin(reinterpret_cast<unsigned long long *>(keys + smp), static_cast<unsigned long long>(k));
+}
+
+// =====================================================================================
+// K4: in-order neighbourhood update of a run of `count` samples whose winners are known.
+//
+// bubble_adapt (som_rout.c:472-506) / gaussian_adapt (:511-549) + adapt_vector
+// (lvq_pak.c:339-351) for iterations batch_start .. batch_start+count-1, applied to
+// every code row in iteration order.  One lane = one code row, QW chunks (4*QW dims) of
+// it held in registers across the whole run, so each touched row is read and written
+// once per run whatever the batch size.  Lattice membership is decided per lane from
+// the winner's coordinates; x is read through wave-uniform loads.
+// =====================================================================================
+template <int QW, bool GAUSS, bool MASKED>
+__global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *__restrict__ rows,
+                                                        const uint8_t *__restrict__ mask,
+                                                        int64_t n_rows, int64_t data_first,
+                                                        int64_t count,
+                                                        const uint64_t *__restrict__ keys,
+                                                        const StepScalars *__restrict__ sc) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t g = blockIdx.x;
+  const int q0 = (blockIdx.y * 4 + wave) * QW;
+  if (q0 >= cb.d4) return;
+  const int64_t row = g * WAVE + lane;
+  const int64_t grow = row + cb.row_offset;
+  const int tx = static_cast<int>(grow % cb.xdim), ty = static_cast<int>(grow / cb.xdim);
+  const bool live = row < cb.n;
+
+  float4 c[QW];
+#pragma unroll
+  for (int j = 0; j < QW; j++)
+    c[j] = (q0 + j < cb.d4) ? *tile_ptr(cb, g, q0 + j, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+  bool dirty = false;
+
+  for (int64_t b = 0; b < count; b++) {
+    const StepScalars s = sc[b];
+    if (s.skip) continue;
+    int64_t widx;
+    if (s.fixed >= 0) widx = s.fixed;
+    else {
+      uint64_t k = keys[b];
+      if (static_cast<uint32_t>(k >> 32) >= FLT_MAX_BITS) continue;   // no winner
+      widx = static_cast<uint32_t>(k);
+    }
+    const int bx = static_cast<int>(widx % cb.xdim), by = static_cast<int>(widx / cb.xdim);
+    const float lsq = lattice_sq(cb.topol, bx, by, tx, ty);
+    float a;
+    bool member;
+    if (GAUSS) { a = gaussian_alpha(lsq, s.thresh, s.alpha); member = live; }
+    else { a = s.alpha; member = live && (lsq <= s.thresh); }
+    if (!__any(member)) continue;
+    const int64_t r = (data_first + b) % n_rows;
+    const float4 *x4 = reinterpret_cast<const float4 *>(rows + r * cb.d);
+    if (member) {
+      dirty = true;
+#pragma unroll
+      for (int j = 0; j < QW; j++) {
+        int q = q0 + j;
+        if (q < cb.d4) {
+          float4 x;
+          if ((cb.d & 3) == 0) x = x4[q];                 // wave-uniform
+          else {
+            const float *xr = rows + r * cb.d;
+            x.x = q * 4 + 0 < cb.d ? xr[q * 4 + 0] : 0.f;
+            x.y = q * 4 + 1 < cb.d ? xr[q * 4 + 1] : 0.f;
+            x.z = q * 4 + 2 < cb.d ? xr[q * 4 + 2] : 0.f;
+            x.w = q * 4 + 3 < cb.d ? xr[q * 4 + 3] : 0.f;
+          }
+          if (MASKED) {
+            const uint8_t *m = mask + r * cb.d + q * 4;
+            float4 n = adapt4(c[j], x, a);
+            if (q * 4 + 0 < cb.d && m[0] == 0) c[j].x = n.x;
+            if (q * 4 + 1 < cb.d && m[1] == 0) c[j].y = n.y;
+            if (q * 4 + 2 < cb.d && m[2] == 0) c[j].z = n.z;
+            if (q * 4 + 3 < cb.d && m[3] == 0) c[j].w = n.w;
+          } else {
+            float4 n = adapt4(c[j], x, a);
+            // padding dims stay 0: x pad = 0 and c pad = 0 give 0 + a*(0-0) = 0
+            c[j] = n;
+          }
+        }
+      }
+    }
+  }
+  if (dirty) {
+#pragma unroll
+    for (int j = 0; j < QW; j++)
+      if (q0 + j < cb.d4) *tile_ptr_w(cb, g, q0 + j, lane) = c[j];
+  }
+}
+
+// =====================================================================================
+// K3: one ONLINE SOM iteration, fused: apply iteration t-1's neighbourhood update to
+// each code row and, in the same pass over the row, accumulate its distance to sample
+// t (som_training's inner loop, som_rout.c:600-662, with find_winner_euc and
+// bubble/gaussian_adapt).  The codebook is therefore read once per iteration instead of
+// twice, and written only where it changed.  The winner of iteration t is folded into
+// slot[t] with a 64-bit atomic min; the next launch (stream order) reads it.
+//   has_prev / has_cur select prologue (no update yet) and flush (no search left).
+// =====================================================================================
+template <bool GAUSS, bool MASKED>
+__global__ __launch_bounds__(256) void k_som_online_step(CbView cb, const float *__restrict__ rows,
+                                                         const uint8_t *__restrict__ mask,
+                                                         int64_t prev_row, int64_t cur_row,
+                                                         int has_prev, int has_cur,
+                                                         const uint64_t *__restrict__ prev_slot,
+                                                         uint64_t *__restrict__ cur_slot,
+                                                         const StepScalars *__restrict__ prev_sc,
+                                                         const StepScalars *__restrict__ cur_sc) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  if (g >= cb.ngroups) return;
+  const int64_t row = g * WAVE + lane;
+  const int64_t grow = row + cb.row_offset;
+  const bool live = row < cb.n;
+
+  bool upd = false;
+  float a = 0.0f;
+  if (has_prev) {
+    const StepScalars s = *prev_sc;
+    int64_t widx = -1;
+    if (!s.skip) {
+      if (s.fixed >= 0) widx = s.fixed;
+      else {
+        uint64_t k = *prev_slot;
+        if (static_cast<uint32_t>(k >> 32) < FLT_MAX_BITS) widx = static_cast<uint32_t>(k);
+      }
+    }
+    if (widx >= 0) {
+      const int tx = static_cast<int>(grow % cb.xdim), ty = static_cast<int>(grow / cb.xdim);
+      const int bx = static_cast<int>(widx % cb.xdim), by = static_cast<int>(widx / cb.xdim);
+      const float lsq = lattice_sq(cb.topol, bx, by, tx, ty);
+      if (GAUSS) { a = gaussian_alpha(lsq, s.thresh, s.alpha); upd = live; }
+      else { a = s.alpha; upd = live && (lsq <= s.thresh); }
+    }
+  }
+  bool search = has_cur;
+  if (has_cur) { const StepScalars s = *cur_sc; if (s.skip || s.fixed >= 0) search = false; }
+  const bool any_upd = __any(upd);
+  if (!any_upd && !search) return;
+
+  const float *xp = rows + prev_row * cb.d;
+  const float *xc = rows + cur_row * cb.d;
+  const uint8_t *mp = MASKED ? mask + prev_row * cb.d : nullptr;
+  const uint8_t *mc = MASKED ? mask + cur_row * cb.d : nullptr;
+  const bool vec = (cb.d & 3) == 0;
+  float acc = 0.0f;
+
+  for (int q = 0; q < cb.d4; q++) {
+    float4 c = *tile_ptr(cb, g, q, lane);
+    if (any_upd) {
+      float4 x;
+      if (vec) x = reinterpret_cast<const float4 *>(xp)[q];
+      else {
+        x.x = q * 4 + 0 < cb.d ? xp[q * 4 + 0] : 0.f;
+        x.y = q * 4 + 1 < cb.d ? xp[q * 4 + 1] : 0.f;
+        x.z = q * 4 + 2 < cb.d ? xp[q * 4 + 2] : 0.f;
+        x.w = q * 4 + 3 < cb.d ? xp[q * 4 + 3] : 0.f;
+      }
+      if (upd) {
+        float4 n = adapt4(c, x, a);
+        if (MASKED) {
+          if (q * 4 + 0 < cb.d && mp[q * 4 + 0] == 0) c.x = n.x;
+          if (q * 4 + 1 < cb.d && mp[q * 4 + 1] == 0) c.y = n.y;
+          if (q * 4 + 2 < cb.d && mp[q * 4 + 2] == 0) c.z = n.z;
+          if (q * 4 + 3 < cb.d && mp[q * 4 + 3] == 0) c.w = n.w;
+        } else {
+          c = n;
+        }
+        *tile_ptr_w(cb, g, q, lane) = c;
+      }
+    }
+    if (search) {
+      float4 x;
+      if (vec) x = reinterpret_cast<const float4 *>(xc)[q];
+      else {
+        x.x = q * 4 + 0 < cb.d ? xc[q * 4 + 0] : 0.f;
+        x.y = q * 4 + 1 < cb.d ? xc[q * 4 + 1] : 0.f;
+        x.z = q * 4 + 2 < cb.d ? xc[q * 4 + 2] : 0.f;
+        x.w = q * 4 + 3 < cb.d ? xc[q * 4 + 3] : 0.f;
+      }
+      if (MASKED) {
+        if (q * 4 + 0 < cb.d && mc[q * 4 + 0] == 0) acc = sq_acc(acc, c.x, x.x);
+        if (q * 4 + 1 < cb.d && mc[q * 4 + 1] == 0) acc = sq_acc(acc, c.y, x.y);
+        if (q * 4 + 2 < cb.d && mc[q * 4 + 2] == 0) acc = sq_acc(acc, c.z, x.z);
+        if (q * 4 + 3 < cb.d && mc[q * 4 + 3] == 0) acc = sq_acc(acc, c.w, x.w);
+      } else {
+        acc = sq_acc(acc, c.x, x.x);
+        acc = sq_acc(acc, c.y, x.y);
+        acc = sq_acc(acc, c.z, x.z);
+        acc = sq_acc(acc, c.w, x.w);
+      }
+    }
+  }
+  if (search) {
+    uint64_t k = live ? make_key(acc, static_cast<uint32_t>(grow)) : KEY_NONE;
+    k = wave_min_u64(k);
+    if (lane == 0)
+      atomicMin(reinterpret_cast<unsigned long long *>(cur_slot), static_cast<unsigned long long>(k));
+  }
+}
+
+// =====================================================================================
+// K5: one ONLINE LVQ iteration, fused the same way: apply iteration t-1's LVQ1 / OLVQ1 /
+// LVQ2.1 / LVQ3 correction (lvq_rout.c:542-555, 650-673, 750-783, 855-896) to the one or
+// two rows it touches, then accumulate every row's distance to sample t and leave this
+// workgroup's two best keys in part[blockIdx.x][2] (knn = 2 uses find_winner_knn's tie
+// order, lvq_pak.c:197).  Every workgroup of the next launch merges all partials
+// itself (a few hundred 8-byte words) -- no extra launch, no grid barrier.
+// =====================================================================================
+struct LvqStep {
+  int32_t kind;        // SOMHIP_LVQ1..3
+  float alpha;         // schedule value for this iteration (unused by OLVQ1)
+  float alpha_clamp;   // OLVQ1: initial alpha (lvq_rout.c:671)
+  float win_ratio;     // (1-w)/(1+w) in fp32 (lvq_rout.c:770)
+  float epsilon;
+  int32_t label;       // the sample's first label
+};
+
+__device__ __forceinline__ void top2_insert(uint64_t &k0, uint64_t &k1, uint64_t v) {
+  if (v < k0) { k1 = k0; k0 = v; }
+  else if (v < k1) k1 = v;
+}
+
+__global__ __launch_bounds__(256) void k_lvq_online_step(CbView cb, const float *__restrict__ rows,
+                                                         const int32_t *__restrict__ clabels,
+                                                         float *__restrict__ talpha,
+                                                         int64_t prev_row, int64_t cur_row,
+                                                         int has_prev, int has_cur, int knn,
+                                                         const uint64_t *__restrict__ prev_part,
+                                                         int prev_nblk,
+                                                         uint64_t *__restrict__ cur_part,
+                                                         uint64_t *__restrict__ prev_final,
+                                                         const LvqStep *__restrict__ prev_st) {
+  __shared__ uint64_t sh[4][2];
+  __shared__ uint64_t shw[2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  const int64_t row = g * WAVE + lane;
+  const bool live = g < cb.ngroups && row < cb.n;
+
+  // --- merge the previous iteration's partial top-2 (identical in every workgroup) ---
+  int64_t u_row[2] = {-1, -1};
+  float u_a[2] = {0.f, 0.f};
+  if (has_prev) {
+    if (wave == 0) {
+      uint64_t k0 = KEY_NONE, k1 = KEY_NONE;
+      for (int j = lane; j < prev_nblk * 2; j += WAVE) top2_insert(k0, k1, prev_part[j]);
+      uint64_t b0 = wave_min_u64(k0);
+      uint64_t mine = (k0 == b0) ? k1 : k0;
+      uint64_t b1 = wave_min_u64(mine);
+      if (lane == 0) { shw[0] = b0; shw[1] = b1; }
+    }
+    __syncthreads();
+    const uint64_t b0 = shw[0], b1 = shw[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { prev_final[0] = b0; prev_final[1] = b1; }
+    const LvqStep st = *prev_st;
+    const uint32_t t0 = static_cast<uint32_t>(b0), t1 = static_cast<uint32_t>(b1);
+    const int64_t i0 = knn == 2 ? static_cast<int64_t>(~t0) : static_cast<int64_t>(t0);
+    const int64_t i1 = static_cast<int64_t>(~t1);
+    if (st.kind == 1) {                                   // LVQ1, lvq_rout.c:552-555
+      u_row[0] = i0;
+      u_a[0] = (clabels[i0] == st.label) ? st.alpha : -st.alpha;
+    } else if (st.kind == 2) {                            // OLVQ1, lvq_rout.c:658-673
+      u_row[0] = i0;
+      float ta = talpha[i0];
+      u_a[0] = (clabels[i0] == st.label) ? ta : -ta;
+    } else {                                              // LVQ2.1 / LVQ3
+      const int l0 = clabels[i0], l1 = clabels[i1];
+      const float d0 = __uint_as_float(static_cast<uint32_t>(b0 >> 32));
+      const float d1 = __uint_as_float(static_cast<uint32_t>(b1 >> 32));
+      if (l0 != l1) {
+        if (l0 == st.label || l1 == st.label) {
+          if ((d0 / d1) > st.win_ratio) {                 // lvq_rout.c:770 / :876
+            int64_t best = i0, nbest = i1;
+            if (l1 == st.label) { best = i1; nbest = i0; }
+            u_row[0] = best;  u_a[0] = st.alpha;
+            u_row[1] = nbest; u_a[1] = -st.alpha;
+          }
+        }
+      } else if (st.kind == 4 && l0 == st.label) {        // lvq_rout.c:890-895
+        float ae = st.alpha * st.epsilon;
+        u_row[0] = i0; u_a[0] = ae;
+        u_row[1] = i1; u_a[1] = ae;
+      }
+    }
+  }
+  const int64_t grow = row + cb.row_offset;
+  // which (if any) correction applies to this lane's row; if both name the same row
+  // (cannot happen: two distinct neighbours) the first wins
+  int which = -1;
+  if (live) { if (grow == u_row[0]) which = 0; else if (grow == u_row[1]) which = 1; }
+  const bool upd = which >= 0;
+  const float a = which == 1 ? u_a[1] : u_a[0];
+  const bool any_upd = __any(upd);
+  const float *xp = rows + prev_row * cb.d;
+  const float *xc = rows + cur_row * cb.d;
+  const bool vec = (cb.d & 3) == 0;
+  float acc = 0.0f;
+  if (g < cb.ngroups && (any_upd || has_cur)) {
+    for (int q = 0; q < cb.d4; q++) {
+      float4 c = *tile_ptr(cb, g, q, lane);
+      if (any_upd) {
+        float4 x;
+        if (vec) x = reinterpret_cast<const float4 *>(xp)[q];
+        else {
+          x.x = q * 4 + 0 < cb.d ? xp[q * 4 + 0] : 0.f;
+          x.y = q * 4 + 1 < cb.d ? xp[q * 4 + 1] : 0.f;
+          x.z = q * 4 + 2 < cb.d ? xp[q * 4 + 2] : 0.f;
+          x.w = q * 4 + 3 < cb.d ? xp[q * 4 + 3] : 0.f;
+        }
+        if (upd) {
+          c = adapt4(c, x, a);
+          *tile_ptr_w(cb, g, q, lane) = c;
+        }
+      }
+      if (has_cur) {
+        float4 x;
+        if (vec) x = reinterpret_cast<const float4 *>(xc)[q];
+        else {
+          x.x = q * 4 + 0 < cb.d ? xc[q * 4 + 0] : 0.f;
+          x.y = q * 4 + 1 < cb.d ? xc[q * 4 + 1] : 0.f;
+          x.z = q * 4 + 2 < cb.d ? xc[q * 4 + 2] : 0.f;
+          x.w = q * 4 + 3 < cb.d ? xc[q * 4 + 3] : 0.f;
+        }
+        acc = sq_acc(acc, c.x, x.x);
+        acc = sq_acc(acc, c.y, x.y);
+        acc = sq_acc(acc, c.z, x.z);
+        acc = sq_acc(acc, c.w, x.w);
+      }
+    }
+  }
+  // OLVQ1: the owner of the corrected row advances its rate (lvq_rout.c:663, :670-672)
+  if (has_prev && upd && which == 0) {
+    const LvqStep st = *prev_st;
+    if (st.kind == 2) {
+      float ta = talpha[grow];
+      if (clabels[grow] == st.label) {
+        ta = ta / (1 + ta);
+      } else {
+        ta = ta / (1 - ta);
+        if (ta > st.alpha_clamp) ta = st.alpha_clamp;
+      }
+      talpha[grow] = ta;
+    }
+  }
+  if (has_cur) {
+    uint32_t tag = static_cast<uint32_t>(grow);
+    uint64_t k = live ? make_key(acc, knn == 2 ? ~tag : tag) : KEY_NONE;
+    uint64_t b0 = wave_min_u64(k);
+    uint64_t mine = (k == b0) ? KEY_NONE : k;
+    uint64_t b1 = wave_min_u64(mine);
+    if (lane == 0) { sh[wave][0] = b0; sh[wave][1] = b1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint64_t k0 = KEY_NONE, k1 = KEY_NONE;
+      for (int w = 0; w < 4; w++) { top2_insert(k0, k1, sh[w][0]); top2_insert(k0, k1, sh[w][1]); }
+      cur_part[blockIdx.x * 2 + 0] = k0;
+      cur_part[blockIdx.x * 2 + 1] = k1;
+    }
+  }
+}
+
+__global__ void k_fill_u64(uint64_t *p, int64_t n, uint64_t v) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace somhip

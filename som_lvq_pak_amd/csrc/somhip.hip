@@ -1,0 +1,793 @@
+// somhip.hip -- C ABI (include/somhip.h) of the MI355X SOM/LVQ engine: host control
+// of the gfx950 kernels in kernels.hpp.  No CPU fallback: every entry point runs on
+// the GPU or fails with a message.
+#include "../../include/somhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "schedule.hpp"
+
+using namespace somhip;
+
+// ---------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+#define HIPCHK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) return fail("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define CHK(expr)          \
+  do {                     \
+    int rc_ = (expr);      \
+    if (rc_) return rc_;   \
+  } while (0)
+
+extern "C" const char *somhip_last_error(void) { return g_err.c_str(); }
+extern "C" int somhip_version(void) { return SOMHIP_VERSION; }
+
+// ---------------------------------------------------------------------------------
+// kernel ids for the timing table
+// ---------------------------------------------------------------------------------
+enum KernelId {
+  KID_SCAN_EXACT = 0,
+  KID_SOM_UPDATE_RUN,
+  KID_SOM_ONLINE_STEP,
+  KID_LVQ_ONLINE_STEP,
+  KID_PACK_SAMPLES,
+  KID_MERGE_TOPK,
+  KID_SCAN_MASKED,
+  KID_LAYOUT,
+  KID_COUNT
+};
+static const char *kKernelNames[KID_COUNT] = {
+    "k_scan_exact", "k_som_update_run", "k_som_online_step", "k_lvq_online_step",
+    "k_pack_samples", "k_merge_topk", "k_scan_masked", "k_layout"};
+extern "C" int somhip_kernel_count(void) { return KID_COUNT; }
+extern "C" const char *somhip_kernel_name(int i) { return (i >= 0 && i < KID_COUNT) ? kKernelNames[i] : ""; }
+
+struct somhip_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool timing = false;
+  struct Pending { int kid; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> pool;
+  int64_t launches[KID_COUNT] = {0};
+  double total_ms[KID_COUNT] = {0};
+  // reusable device scratch
+  void *scratch[8] = {nullptr};
+  size_t scratch_bytes[8] = {0};
+};
+
+static int engine_scratch(somhip_engine *e, int slot, size_t bytes, void **out) {
+  if (e->scratch_bytes[slot] < bytes) {
+    if (e->scratch[slot]) HIPCHK(hipFree(e->scratch[slot]));
+    e->scratch[slot] = nullptr;
+    e->scratch_bytes[slot] = 0;
+    size_t want = std::max(bytes, (size_t)4096);
+    HIPCHK(hipMalloc(&e->scratch[slot], want));
+    e->scratch_bytes[slot] = want;
+  }
+  *out = e->scratch[slot];
+  return 0;
+}
+
+static int timing_flush(somhip_engine *e) {
+  if (e->pending.empty()) return 0;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (auto &p : e->pending) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
+    e->launches[p.kid]++;
+    e->total_ms[p.kid] += ms;
+    e->pool.push_back(p.a);
+    e->pool.push_back(p.b);
+  }
+  e->pending.clear();
+  return 0;
+}
+
+struct LaunchTimer {   // HIP events on the engine's own stream around one launch
+  somhip_engine *e;
+  int kid;
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on = false;
+  LaunchTimer(somhip_engine *e_, int kid_) : e(e_), kid(kid_) {
+    if (!e->timing) return;
+    auto get = [&](hipEvent_t *ev) {
+      if (!e->pool.empty()) { *ev = e->pool.back(); e->pool.pop_back(); return true; }
+      return hipEventCreate(ev) == hipSuccess;
+    };
+    if (get(&a) && get(&b)) { on = true; (void)hipEventRecord(a, e->stream); }
+  }
+  ~LaunchTimer() {
+    if (!on) return;
+    (void)hipEventRecord(b, e->stream);
+    e->pending.push_back({kid, a, b});
+    if (e->pending.size() >= 2048) (void)timing_flush(e);
+  }
+};
+
+// ---------------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------------
+extern "C" int somhip_engine_create(int device, somhip_engine **out) {
+  if (!out) return fail("somhip_engine_create: null out");
+  int ndev = 0;
+  hipError_t er = hipGetDeviceCount(&ndev);
+  if (er != hipSuccess || ndev <= 0)
+    return fail("somhip_engine_create: no HIP device available (%s) -- this engine has no CPU path",
+                er == hipSuccess ? "device count 0" : hipGetErrorString(er));
+  if (device < 0 || device >= ndev) return fail("somhip_engine_create: device %d out of range (%d)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  somhip_engine *e = new somhip_engine();
+  e->device = device;
+  HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  *out = e;
+  return 0;
+}
+extern "C" void somhip_engine_destroy(somhip_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto ev : e->pool) (void)hipEventDestroy(ev);
+  for (int i = 0; i < 8; i++) if (e->scratch[i]) (void)hipFree(e->scratch[i]);
+  (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+extern "C" void *somhip_engine_stream(somhip_engine *e) { return e ? (void *)e->stream : nullptr; }
+extern "C" int somhip_engine_sync(somhip_engine *e) {
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+extern "C" int somhip_timing_enable(somhip_engine *e, int on) { CHK(timing_flush(e)); e->timing = on != 0; return 0; }
+extern "C" int somhip_timing_reset(somhip_engine *e) {
+  CHK(timing_flush(e));
+  for (int i = 0; i < KID_COUNT; i++) { e->launches[i] = 0; e->total_ms[i] = 0; }
+  return 0;
+}
+extern "C" int somhip_timing_get(somhip_engine *e, int k, int64_t *launches, double *total_ms) {
+  if (k < 0 || k >= KID_COUNT) return fail("somhip_timing_get: bad kernel id %d", k);
+  CHK(timing_flush(e));
+  if (launches) *launches = e->launches[k];
+  if (total_ms) *total_ms = e->total_ms[k];
+  return 0;
+}
+extern "C" int somhip_device_alloc(somhip_engine *e, int64_t bytes, void **p) {
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipMalloc(p, (size_t)std::max<int64_t>(bytes, 16)));
+  return 0;
+}
+extern "C" int somhip_device_free(somhip_engine *e, void *p) {
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipFree(p));
+  return 0;
+}
+extern "C" int somhip_copy_to_host(somhip_engine *e, void *dst, const void *src, int64_t bytes) {
+  HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+extern "C" int somhip_copy_to_device(somhip_engine *e, void *dst, const void *src, int64_t bytes) {
+  HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// codebook / dataset mirrors
+// ---------------------------------------------------------------------------------
+struct somhip_codebook {
+  somhip_engine *e = nullptr;
+  CbView v{};
+  int ydim = 0;
+  int64_t n_global = 0;
+  int32_t *d_labels = nullptr;     // [n] local rows
+  float *d_talpha = nullptr;       // [n] OLVQ1 rates
+};
+struct somhip_dataset {
+  somhip_engine *e = nullptr;
+  const float *d_rows = nullptr;
+  bool owns_rows = false;
+  int64_t n = 0;
+  int d = 0;
+  uint8_t *d_mask = nullptr;
+  std::vector<uint8_t> all_masked;   // host: 1 if every component of the row is masked
+  std::vector<int32_t> labels;       // host copies of the per-row scalars
+  std::vector<int16_t> weight;
+  std::vector<int16_t> fixed_xy;
+};
+
+static int upload_rows(somhip_codebook *cb, const float *rows) {
+  somhip_engine *e = cb->e;
+  void *stage;
+  size_t bytes = sizeof(float) * (size_t)cb->v.n * cb->v.d;
+  CHK(engine_scratch(e, 0, bytes, &stage));
+  HIPCHK(hipMemcpyAsync(stage, rows, bytes, hipMemcpyHostToDevice, e->stream));
+  {
+    LaunchTimer t(e, KID_LAYOUT);
+    hipLaunchKernelGGL(k_rows_to_tiles, dim3((unsigned)cb->v.ngroups), dim3(256), 0, e->stream,
+                       (const float *)stage, cb->v);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int somhip_codebook_create(somhip_engine *e, const float *rows, const int32_t *labels,
+                                      int64_t n_rows, int dim, int topol, int neigh, int xdim,
+                                      int ydim, int64_t row_offset, int64_t n_global,
+                                      somhip_codebook **out) {
+  if (!e || !rows || !out) return fail("somhip_codebook_create: null argument");
+  if (n_rows <= 0 || dim <= 0) return fail("somhip_codebook_create: empty codebook (%lld x %d)", (long long)n_rows, dim);
+  if (n_global < row_offset + n_rows) return fail("somhip_codebook_create: shard [%lld,%lld) outside %lld rows",
+                                                  (long long)row_offset, (long long)(row_offset + n_rows), (long long)n_global);
+  if (n_global >= 0xFFFFFFFFll) return fail("somhip_codebook_create: more than 2^32-2 rows");
+  if (topol >= SOMHIP_TOPOL_HEXA && (xdim <= 0 || ydim <= 0 || (int64_t)xdim * ydim != n_global))
+    return fail("somhip_codebook_create: map %dx%d does not have %lld units", xdim, ydim, (long long)n_global);
+  HIPCHK(hipSetDevice(e->device));
+  somhip_codebook *cb = new somhip_codebook();
+  cb->e = e;
+  cb->v.n = n_rows;
+  cb->v.ngroups = (n_rows + WAVE - 1) / WAVE;
+  cb->v.d = dim;
+  cb->v.d4 = (dim + 3) / 4;
+  cb->v.row_offset = row_offset;
+  cb->v.xdim = xdim > 0 ? xdim : 1;
+  cb->v.topol = topol;
+  cb->v.neigh = neigh;
+  cb->ydim = ydim;
+  cb->n_global = n_global;
+  size_t tile_bytes = (size_t)cb->v.ngroups * cb->v.d4 * WAVE * 4 * sizeof(float);
+  HIPCHK(hipMalloc((void **)&cb->v.tiles, tile_bytes));
+  int rc = upload_rows(cb, rows);
+  if (rc) { somhip_codebook_destroy(cb); return rc; }
+  if (labels) {
+    HIPCHK(hipMalloc((void **)&cb->d_labels, sizeof(int32_t) * (size_t)n_rows));
+    HIPCHK(hipMemcpy(cb->d_labels, labels, sizeof(int32_t) * (size_t)n_rows, hipMemcpyHostToDevice));
+  }
+  *out = cb;
+  return 0;
+}
+extern "C" int somhip_codebook_upload(somhip_codebook *cb, const float *rows) {
+  HIPCHK(hipSetDevice(cb->e->device));
+  return upload_rows(cb, rows);
+}
+extern "C" int somhip_codebook_download(somhip_codebook *cb, float *rows) {
+  somhip_engine *e = cb->e;
+  HIPCHK(hipSetDevice(e->device));
+  void *stage;
+  size_t bytes = sizeof(float) * (size_t)cb->v.n * cb->v.d;
+  CHK(engine_scratch(e, 0, bytes, &stage));
+  {
+    LaunchTimer t(e, KID_LAYOUT);
+    hipLaunchKernelGGL(k_tiles_to_rows, dim3((unsigned)cb->v.ngroups), dim3(256), 0, e->stream,
+                       (float *)stage, cb->v);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(rows, stage, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+extern "C" void somhip_codebook_destroy(somhip_codebook *cb) {
+  if (!cb) return;
+  (void)hipSetDevice(cb->e->device);
+  (void)hipStreamSynchronize(cb->e->stream);
+  if (cb->v.tiles) (void)hipFree(cb->v.tiles);
+  if (cb->d_labels) (void)hipFree(cb->d_labels);
+  if (cb->d_talpha) (void)hipFree(cb->d_talpha);
+  delete cb;
+}
+
+extern "C" int somhip_dataset_create(somhip_engine *e, const float *rows, int64_t n_rows, int dim,
+                                     const uint8_t *mask, const int32_t *labels,
+                                     const int16_t *weight, const int16_t *fixed_xy,
+                                     somhip_dataset **out) {
+  if (!e || !rows || !out) return fail("somhip_dataset_create: null argument");
+  if (n_rows <= 0 || dim <= 0) return fail("somhip_dataset_create: empty data set");
+  HIPCHK(hipSetDevice(e->device));
+  somhip_dataset *ds = new somhip_dataset();
+  ds->e = e; ds->n = n_rows; ds->d = dim; ds->owns_rows = true;
+  size_t bytes = sizeof(float) * (size_t)n_rows * dim;
+  float *dr = nullptr;
+  // 16 spare bytes: wave-uniform float4 reads of the last row never leave the buffer
+  HIPCHK(hipMalloc((void **)&dr, bytes + 16));
+  HIPCHK(hipMemcpy(dr, rows, bytes, hipMemcpyHostToDevice));
+  ds->d_rows = dr;
+  if (mask) {
+    bool any = false;
+    ds->all_masked.assign((size_t)n_rows, 0);
+    for (int64_t r = 0; r < n_rows; r++) {
+      int cnt = 0;
+      for (int i = 0; i < dim; i++) cnt += mask[r * dim + i] != 0;
+      any |= cnt > 0;
+      ds->all_masked[(size_t)r] = cnt == dim;
+    }
+    if (any) {
+      HIPCHK(hipMalloc((void **)&ds->d_mask, (size_t)n_rows * dim));
+      HIPCHK(hipMemcpy(ds->d_mask, mask, (size_t)n_rows * dim, hipMemcpyHostToDevice));
+    } else {
+      ds->all_masked.clear();
+    }
+  }
+  if (labels) ds->labels.assign(labels, labels + n_rows);
+  if (weight) ds->weight.assign(weight, weight + n_rows);
+  if (fixed_xy) ds->fixed_xy.assign(fixed_xy, fixed_xy + 2 * n_rows);
+  *out = ds;
+  return 0;
+}
+extern "C" int somhip_dataset_wrap_device(somhip_engine *e, const float *dev_rows, int64_t n_rows,
+                                          int dim, somhip_dataset **out) {
+  if (!e || !dev_rows || !out) return fail("somhip_dataset_wrap_device: null argument");
+  somhip_dataset *ds = new somhip_dataset();
+  ds->e = e; ds->n = n_rows; ds->d = dim; ds->d_rows = dev_rows; ds->owns_rows = false;
+  *out = ds;
+  return 0;
+}
+extern "C" void somhip_dataset_destroy(somhip_dataset *ds) {
+  if (!ds) return;
+  (void)hipSetDevice(ds->e->device);
+  (void)hipStreamSynchronize(ds->e->stream);
+  if (ds->owns_rows && ds->d_rows) (void)hipFree((void *)ds->d_rows);
+  if (ds->d_mask) (void)hipFree(ds->d_mask);
+  delete ds;
+}
+
+// ---------------------------------------------------------------------------------
+// winner scans
+// ---------------------------------------------------------------------------------
+constexpr int SCAN_S = 32;     // samples per workgroup tile
+
+static int check_pair(const somhip_codebook *cb, const somhip_dataset *ds, const char *who) {
+  if (!cb || !ds) return fail("%s: null handle", who);
+  if (cb->e != ds->e) return fail("%s: codebook and data belong to different engines", who);
+  if (cb->v.d != ds->d)
+    return fail("%s: code dimension (%d) != data dimension (%d)", who, cb->v.d, ds->d);   // som_rout.c:591-596
+  return 0;
+}
+
+// keys[count] <- exact nearest row per sample, FIRST tie rule, local shard
+static int scan_keys_top1(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
+                          uint64_t *d_keys) {
+  somhip_engine *e = cb->e;
+  HIPCHK(hipMemsetAsync(d_keys, 0xFF, sizeof(uint64_t) * (size_t)count, e->stream));
+  if (ds->d_mask) {
+    for (int64_t off = 0; off < count; off += 32768) {      // grid.y limit
+      int64_t c = std::min<int64_t>(32768, count - off);
+      LaunchTimer t(e, KID_SCAN_MASKED);
+      dim3 grid((unsigned)((cb->v.ngroups + 3) / 4), (unsigned)c);
+      hipLaunchKernelGGL(k_scan_masked, grid, dim3(256), 0, e->stream, cb->v, ds->d_rows, ds->d_mask,
+                         ds->n, (first + off) % ds->n, c, 0, d_keys + off);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int64_t nsb = (count + SCAN_S - 1) / SCAN_S;
+  void *xt;
+  CHK(engine_scratch(e, 1, sizeof(float4) * (size_t)nsb * cb->v.d4 * SCAN_S, &xt));
+  {
+    LaunchTimer t(e, KID_PACK_SAMPLES);
+    hipLaunchKernelGGL(k_pack_samples<SCAN_S>, dim3((unsigned)nsb), dim3(256), 0, e->stream,
+                       ds->d_rows, ds->n, ds->d, cb->v.d4, first, count, (float4 *)xt);
+  }
+  HIPCHK(hipGetLastError());
+  {
+    LaunchTimer t(e, KID_SCAN_EXACT);
+    dim3 grid((unsigned)nsb, (unsigned)((cb->v.ngroups + 3) / 4));
+    hipLaunchKernelGGL((k_scan_exact<SCAN_S, 1, 1>), grid, dim3(256), 0, e->stream, cb->v,
+                       (const float4 *)xt, count, 0, d_keys, (uint64_t *)nullptr);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <int K>
+static int scan_keys_topk(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
+                          uint64_t *d_keys /*[count][K]*/) {
+  somhip_engine *e = cb->e;
+  int64_t nsb = (count + SCAN_S - 1) / SCAN_S;
+  int nblk = (int)((cb->v.ngroups + 3) / 4);
+  void *xt, *part;
+  CHK(engine_scratch(e, 1, sizeof(float4) * (size_t)nsb * cb->v.d4 * SCAN_S, &xt));
+  CHK(engine_scratch(e, 2, sizeof(uint64_t) * (size_t)count * nblk * K, &part));
+  {
+    LaunchTimer t(e, KID_PACK_SAMPLES);
+    hipLaunchKernelGGL(k_pack_samples<SCAN_S>, dim3((unsigned)nsb), dim3(256), 0, e->stream,
+                       ds->d_rows, ds->n, ds->d, cb->v.d4, first, count, (float4 *)xt);
+  }
+  HIPCHK(hipGetLastError());
+  {
+    LaunchTimer t(e, KID_SCAN_EXACT);
+    dim3 grid((unsigned)nsb, (unsigned)nblk);
+    hipLaunchKernelGGL((k_scan_exact<SCAN_S, 1, K>), grid, dim3(256), 0, e->stream, cb->v,
+                       (const float4 *)xt, count, 1, (uint64_t *)nullptr, (uint64_t *)part);
+  }
+  HIPCHK(hipGetLastError());
+  {
+    LaunchTimer t(e, KID_MERGE_TOPK);
+    hipLaunchKernelGGL(k_merge_topk<K>, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, e->stream,
+                       (const uint64_t *)part, nblk, count, d_keys);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int somhip_batch_winner_keys(somhip_codebook *cb, somhip_dataset *ds, int64_t first,
+                                        int64_t count, uint64_t *dev_keys) {
+  CHK(check_pair(cb, ds, "somhip_batch_winner_keys"));
+  if (count <= 0) return 0;
+  HIPCHK(hipSetDevice(cb->e->device));
+  return scan_keys_top1(cb, ds, first, count, dev_keys);
+}
+
+static void decode_key(uint64_t k, bool inverted, int32_t *index, float *diff) {
+  uint32_t bits = (uint32_t)(k >> 32);
+  uint32_t tag = (uint32_t)k;
+  if (bits >= FLT_MAX_BITS) { *index = -1; *diff = -1.0f; return; }   // nothing beat FLT_MAX (lvq_pak.c:56)
+  *index = (int32_t)(inverted ? ~tag : tag);
+  memcpy(diff, &bits, 4);
+}
+
+extern "C" int somhip_find_winners(somhip_codebook *cb, somhip_dataset *ds, int64_t first,
+                                   int64_t count, int knn, int tie, int32_t *index, float *diff,
+                                   int32_t *ret) {
+  CHK(check_pair(cb, ds, "somhip_find_winners"));
+  if (knn < 1 || knn > 8) return fail("somhip_find_winners: knn %d not in 1..8", knn);
+  if (!index || !diff) return fail("somhip_find_winners: null output");
+  if (count <= 0) return 0;
+  somhip_engine *e = cb->e;
+  HIPCHK(hipSetDevice(e->device));
+  // find_winner_knn(knn == 1) IS find_winner_euc (lvq_pak.c:160-161)
+  const bool knn_rule = (tie == SOMHIP_TIE_KNN) && knn >= 2;
+  if (!knn_rule && knn != 1) return fail("somhip_find_winners: knn > 1 needs SOMHIP_TIE_KNN");
+  if (ds->d_mask && knn_rule) return fail("somhip_find_winners: k-NN with masked samples is not implemented");
+  const int64_t CH = 16384;
+  const int KK = knn == 1 ? 1 : knn == 2 ? 2 : knn <= 4 ? 4 : 8;
+  void *dk;
+  CHK(engine_scratch(e, 3, sizeof(uint64_t) * (size_t)std::min(CH, count) * KK, &dk));
+  std::vector<uint64_t> hk((size_t)std::min(CH, count) * KK);
+  for (int64_t off = 0; off < count; off += CH) {
+    int64_t c = std::min(CH, count - off);
+    int64_t f = (first + off) % ds->n;
+    if (!knn_rule) CHK(scan_keys_top1(cb, ds, f, c, (uint64_t *)dk));
+    else if (KK == 2) CHK(scan_keys_topk<2>(cb, ds, f, c, (uint64_t *)dk));
+    else if (KK == 4) CHK(scan_keys_topk<4>(cb, ds, f, c, (uint64_t *)dk));
+    else CHK(scan_keys_topk<8>(cb, ds, f, c, (uint64_t *)dk));
+    HIPCHK(hipMemcpyAsync(hk.data(), dk, sizeof(uint64_t) * (size_t)c * KK, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int64_t i = 0; i < c; i++) {
+      int64_t r = (f + i) % ds->n;
+      bool empty = !ds->all_masked.empty() && ds->all_masked[(size_t)r];
+      for (int k = 0; k < knn; k++) {
+        int32_t *pi = index + (off + i) * knn + k;
+        float *pd = diff + (off + i) * knn + k;
+        if (empty) { *pi = -2; *pd = -1.0f; }
+        else decode_key(hk[(size_t)i * KK + k], knn_rule, pi, pd);
+      }
+      if (ret) ret[off + i] = empty ? 0 : knn;
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// som_training
+// ---------------------------------------------------------------------------------
+static int som_scalars(const somhip_codebook *cb, const somhip_dataset *ds, const somhip_som_params *p,
+                       int64_t it0, int64_t cnt, int64_t row0, StepScalars *out) {
+  const bool gauss = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN;
+  for (int64_t j = 0; j < cnt; j++) {
+    int64_t le = it0 + j, r = (row0 + j) % ds->n;
+    float trad = radius_at(le, p->length, p->radius);
+    float talp = alpha_at(p->alpha_type, le, p->length, p->alpha);
+    float w = ds->weight.empty() ? 0.0f : (float)ds->weight[(size_t)r];
+    if (w > 0.0f && p->use_weights) talp = weighted_alpha(talp, w);
+    StepScalars s;
+    s.alpha = talp;
+    s.thresh = gauss ? trad : bubble_threshold(trad);
+    s.fixed = -1;
+    s.skip = (!ds->all_masked.empty() && ds->all_masked[(size_t)r]) ? 1 : 0;
+    if (p->use_fixed && !ds->fixed_xy.empty() && ds->fixed_xy[(size_t)(2 * r)] >= 0) {
+      int fx = ds->fixed_xy[(size_t)(2 * r)], fy = ds->fixed_xy[(size_t)(2 * r + 1)];
+      s.fixed = fy * cb->v.xdim + fx;      // inverse of som_rout.c:641-642
+      s.skip = 0;
+    }
+    out[j] = s;
+  }
+  return 0;
+}
+
+template <bool G, bool M>
+static void launch_online(somhip_engine *e, const somhip_codebook *cb, const somhip_dataset *ds,
+                          int64_t prev_row, int64_t cur_row, int has_prev, int has_cur,
+                          const uint64_t *prev_slot, uint64_t *cur_slot, const StepScalars *prev_sc,
+                          const StepScalars *cur_sc) {
+  LaunchTimer t(e, KID_SOM_ONLINE_STEP);
+  hipLaunchKernelGGL((k_som_online_step<G, M>), dim3((unsigned)((cb->v.ngroups + 3) / 4)), dim3(256), 0,
+                     e->stream, cb->v, ds->d_rows, (const uint8_t *)ds->d_mask, prev_row, cur_row,
+                     has_prev, has_cur, prev_slot, cur_slot, prev_sc, cur_sc);
+}
+
+static int som_train_online(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
+                            int32_t *trace_index, float *trace_diff) {
+  somhip_engine *e = cb->e;
+  const int64_t CH = 4096;
+  const bool G = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN, M = ds->d_mask != nullptr;
+  void *dslot, *dsc;
+  // entry 0 of both arrays carries the last iteration of the previous chunk
+  CHK(engine_scratch(e, 3, sizeof(uint64_t) * (size_t)(CH + 1), &dslot));
+  CHK(engine_scratch(e, 4, sizeof(StepScalars) * (size_t)(CH + 1), &dsc));
+  uint64_t *slot = (uint64_t *)dslot;
+  StepScalars *sc = (StepScalars *)dsc;
+  std::vector<StepScalars> hsc((size_t)CH + 1);
+  std::vector<uint64_t> hslot((size_t)CH + 1);
+  int64_t prev_row = 0;
+  bool have_prev = false;
+  for (int64_t off = 0; off < p->count; off += CH) {
+    int64_t c = std::min(CH, p->count - off);
+    int64_t it0 = p->start_iter + off, row0 = (p->data_first + off) % ds->n;
+    CHK(som_scalars(cb, ds, p, it0, c, row0, hsc.data() + 1));
+    HIPCHK(hipMemcpyAsync(sc + 1, hsc.data() + 1, sizeof(StepScalars) * (size_t)c, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(slot + 1, 0xFF, sizeof(uint64_t) * (size_t)c, e->stream));
+    for (int64_t j = 0; j < c; j++) {
+      int64_t cur_row = (row0 + j) % ds->n;
+      int hp = have_prev ? 1 : 0;
+#define GO(GG, MM) launch_online<GG, MM>(e, cb, ds, prev_row, cur_row, hp, 1, slot + j, slot + j + 1, sc + j, sc + j + 1)
+      if (G && M) GO(true, true); else if (G) GO(true, false); else if (M) GO(false, true); else GO(false, false);
+#undef GO
+      prev_row = cur_row;
+      have_prev = true;
+    }
+    HIPCHK(hipGetLastError());
+    if (trace_index || trace_diff) {
+      HIPCHK(hipMemcpyAsync(hslot.data(), slot + 1, sizeof(uint64_t) * (size_t)c, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      for (int64_t j = 0; j < c; j++) {
+        int32_t idx; float df;
+        const StepScalars &s = hsc[(size_t)j + 1];
+        if (s.fixed >= 0) { idx = -3; df = -1.0f; }
+        else if (s.skip) { idx = -2; df = -1.0f; }
+        else decode_key(hslot[(size_t)j], false, &idx, &df);
+        if (trace_index) trace_index[off + j] = idx;
+        if (trace_diff) trace_diff[off + j] = df;
+      }
+    }
+    // carry the last iteration's slot + scalars into entry 0 for the next chunk / the flush
+    HIPCHK(hipMemcpyAsync(slot, slot + c, sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(sc, sc + c, sizeof(StepScalars), hipMemcpyDeviceToDevice, e->stream));
+    // the host staging vectors are reused by the next chunk
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  if (have_prev) {   // flush: apply the last iteration's update
+#define GO(GG, MM) launch_online<GG, MM>(e, cb, ds, prev_row, prev_row, 1, 0, slot, slot, sc, sc)
+    if (G && M) GO(true, true); else if (G) GO(true, false); else if (M) GO(false, true); else GO(false, false);
+#undef GO
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+static int som_update_run(somhip_codebook *cb, somhip_dataset *ds, int64_t data_first, int64_t count,
+                          const uint64_t *d_keys, const StepScalars *d_sc) {
+  somhip_engine *e = cb->e;
+  const bool G = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN, M = ds->d_mask != nullptr;
+  constexpr int QW = 16;
+  dim3 grid((unsigned)cb->v.ngroups, (unsigned)((cb->v.d4 + 4 * QW - 1) / (4 * QW)));
+  LaunchTimer t(e, KID_SOM_UPDATE_RUN);
+#define GO(GG, MM)                                                                                   \
+  hipLaunchKernelGGL((k_som_update_run<QW, GG, MM>), grid, dim3(256), 0, e->stream, cb->v, ds->d_rows, \
+                     (const uint8_t *)ds->d_mask, ds->n, data_first, count, d_keys, d_sc)
+  if (G && M) GO(true, true); else if (G) GO(true, false); else if (M) GO(false, true); else GO(false, false);
+#undef GO
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int somhip_som_batch_update(somhip_codebook *cb, somhip_dataset *ds,
+                                       const somhip_som_params *p, int64_t batch_start_iter,
+                                       int64_t count, int64_t data_first, const uint64_t *dev_keys) {
+  CHK(check_pair(cb, ds, "somhip_som_batch_update"));
+  if (cb->v.topol < SOMHIP_TOPOL_HEXA) return fail("somhip_som_batch_update: codebook is not a map");
+  if (count <= 0) return 0;
+  somhip_engine *e = cb->e;
+  HIPCHK(hipSetDevice(e->device));
+  std::vector<StepScalars> hsc((size_t)count);
+  CHK(som_scalars(cb, ds, p, batch_start_iter, count, data_first % ds->n, hsc.data()));
+  void *dsc;
+  CHK(engine_scratch(e, 4, sizeof(StepScalars) * (size_t)count, &dsc));
+  HIPCHK(hipMemcpyAsync(dsc, hsc.data(), sizeof(StepScalars) * (size_t)count, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));   // hsc goes out of scope
+  return som_update_run(cb, ds, data_first % ds->n, count, dev_keys, (const StepScalars *)dsc);
+}
+
+static int som_train_batched(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
+                             int32_t *trace_index, float *trace_diff) {
+  somhip_engine *e = cb->e;
+  const int64_t B = p->batch;
+  void *dkeys, *dsc;
+  CHK(engine_scratch(e, 3, sizeof(uint64_t) * (size_t)B, &dkeys));
+  CHK(engine_scratch(e, 4, sizeof(StepScalars) * (size_t)B, &dsc));
+  std::vector<StepScalars> hsc((size_t)B);
+  std::vector<uint64_t> hk((size_t)B);
+  // batches are aligned to the schedule (iteration 0, B, 2B, ...), as in the oracle
+  for (int64_t off = 0; off < p->count;) {
+    int64_t it0 = p->start_iter + off;
+    int64_t c = std::min(B - (it0 % B), p->count - off);
+    int64_t row0 = (p->data_first + off) % ds->n;
+    CHK(som_scalars(cb, ds, p, it0, c, row0, hsc.data()));
+    HIPCHK(hipMemcpyAsync(dsc, hsc.data(), sizeof(StepScalars) * (size_t)c, hipMemcpyHostToDevice, e->stream));
+    CHK(scan_keys_top1(cb, ds, row0, c, (uint64_t *)dkeys));
+    CHK(som_update_run(cb, ds, row0, c, (const uint64_t *)dkeys, (const StepScalars *)dsc));
+    if (trace_index || trace_diff) {
+      HIPCHK(hipMemcpyAsync(hk.data(), dkeys, sizeof(uint64_t) * (size_t)c, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (trace_index || trace_diff) {
+      for (int64_t j = 0; j < c; j++) {
+        int32_t idx; float df;
+        if (hsc[(size_t)j].fixed >= 0) { idx = -3; df = -1.0f; }
+        else if (hsc[(size_t)j].skip) { idx = -2; df = -1.0f; }
+        else decode_key(hk[(size_t)j], false, &idx, &df);
+        if (trace_index) trace_index[off + j] = idx;
+        if (trace_diff) trace_diff[off + j] = df;
+      }
+    }
+    off += c;
+  }
+  return 0;
+}
+
+extern "C" int somhip_som_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
+                                int32_t *trace_index, float *trace_diff) {
+  CHK(check_pair(cb, ds, "somhip_som_train"));
+  if (!p) return fail("somhip_som_train: null params");
+  if (cb->v.topol < SOMHIP_TOPOL_HEXA || (cb->v.neigh != SOMHIP_NEIGH_BUBBLE && cb->v.neigh != SOMHIP_NEIGH_GAUSSIAN))
+    return fail("som_training: can't set SOM parameters");                 // som_rout.c:576-580
+  if (p->length <= 0 || p->count < 0 || p->start_iter < 0 || p->start_iter + p->count > p->length)
+    return fail("somhip_som_train: iterations [%lld,%lld) outside schedule of %lld",
+                (long long)p->start_iter, (long long)(p->start_iter + p->count), (long long)p->length);
+  if (cb->v.row_offset != 0 || cb->n_global != cb->v.n)
+    return fail("somhip_som_train: sharded codebook -- use somhip_batch_winner_keys + somhip_som_batch_update");
+  if (p->count == 0) return 0;
+  HIPCHK(hipSetDevice(cb->e->device));
+  if (p->batch <= 1) return som_train_online(cb, ds, p, trace_index, trace_diff);
+  return som_train_batched(cb, ds, p, trace_index, trace_diff);
+}
+
+// ---------------------------------------------------------------------------------
+// lvq*_training
+// ---------------------------------------------------------------------------------
+extern "C" int somhip_lvq_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_lvq_params *p,
+                                float *talpha, int32_t *trace_index, float *trace_diff) {
+  CHK(check_pair(cb, ds, "somhip_lvq_train"));
+  if (!p) return fail("somhip_lvq_train: null params");
+  if (p->kind < SOMHIP_LVQ1 || p->kind > SOMHIP_LVQ3) return fail("Unknown LVQ type %d", p->kind);
+  if (!cb->d_labels) return fail("somhip_lvq_train: codebook has no labels");
+  if (ds->labels.empty()) return fail("somhip_lvq_train: data has no labels");
+  if (ds->d_mask) return fail("somhip_lvq_train: masked samples are not supported by the LVQ loops");
+  if (p->kind == SOMHIP_OLVQ1 && !talpha) return fail("somhip_lvq_train: OLVQ1 needs talpha");
+  if (p->length <= 0 || p->count < 0 || p->start_iter + p->count > p->length)
+    return fail("somhip_lvq_train: iterations outside schedule");
+  if (cb->v.row_offset != 0 || cb->n_global != cb->v.n) return fail("somhip_lvq_train: sharded codebook not supported");
+  const int knn = (p->kind >= SOMHIP_LVQ2) ? 2 : 1;
+  if (knn == 2 && cb->v.n < 2) return fail("somhip_lvq_train: LVQ2/LVQ3 need at least two code rows");
+  if (p->count == 0) return 0;
+  somhip_engine *e = cb->e;
+  HIPCHK(hipSetDevice(e->device));
+  if (p->kind == SOMHIP_OLVQ1) {
+    if (!cb->d_talpha) HIPCHK(hipMalloc((void **)&cb->d_talpha, sizeof(float) * (size_t)cb->v.n));
+    HIPCHK(hipMemcpyAsync(cb->d_talpha, talpha, sizeof(float) * (size_t)cb->v.n, hipMemcpyHostToDevice, e->stream));
+  }
+  const int64_t CH = 4096;
+  const int nblk = (int)((cb->v.ngroups + 3) / 4);
+  void *dpart, *dfinal, *dst;
+  CHK(engine_scratch(e, 2, sizeof(uint64_t) * (size_t)nblk * 2 * 2, &dpart));
+  CHK(engine_scratch(e, 3, sizeof(uint64_t) * (size_t)(CH + 1) * 2, &dfinal));
+  CHK(engine_scratch(e, 4, sizeof(LvqStep) * (size_t)(CH + 1), &dst));
+  uint64_t *part[2] = {(uint64_t *)dpart, (uint64_t *)dpart + (size_t)nblk * 2};
+  uint64_t *fin = (uint64_t *)dfinal;
+  LvqStep *st = (LvqStep *)dst;
+  std::vector<LvqStep> hst((size_t)CH + 1);
+  std::vector<uint64_t> hfin((size_t)(CH + 1) * 2);
+  const float ratio = (1 - p->winlen) / (1 + p->winlen);                  // lvq_rout.c:770, fp32
+  int64_t prev_row = 0;
+  bool have_prev = false;
+  int flip = 0;
+  // fin[j] receives the merged winners of chunk-iteration j-1 when iteration j launches;
+  // the last one of a chunk lands in fin[c] when the next chunk's first launch (or the
+  // flush) runs, so traces are read one launch late.
+  int64_t pending_trace = -1;   // global offset of the iteration whose winners arrive next
+  for (int64_t off = 0; off < p->count; off += CH) {
+    int64_t c = std::min(CH, p->count - off);
+    int64_t it0 = p->start_iter + off, row0 = (p->data_first + off) % ds->n;
+    for (int64_t j = 0; j < c; j++) {
+      int64_t r = (row0 + j) % ds->n;
+      LvqStep s;
+      s.kind = p->kind;
+      s.alpha = alpha_at(p->alpha_type, it0 + j, p->length, p->alpha);
+      s.alpha_clamp = p->alpha;
+      s.win_ratio = ratio;
+      s.epsilon = p->epsilon;
+      s.label = ds->labels[(size_t)r];
+      hst[(size_t)j + 1] = s;
+    }
+    HIPCHK(hipMemcpyAsync(st + 1, hst.data() + 1, sizeof(LvqStep) * (size_t)c, hipMemcpyHostToDevice, e->stream));
+    for (int64_t j = 0; j < c; j++) {
+      int64_t cur_row = (row0 + j) % ds->n;
+      {
+        LaunchTimer t(e, KID_LVQ_ONLINE_STEP);
+        hipLaunchKernelGGL(k_lvq_online_step, dim3((unsigned)nblk), dim3(256), 0, e->stream, cb->v,
+                           ds->d_rows, (const int32_t *)cb->d_labels, cb->d_talpha, prev_row, cur_row,
+                           have_prev ? 1 : 0, 1, knn, (const uint64_t *)part[flip], nblk, part[flip ^ 1],
+                           fin + 2 * j, (const LvqStep *)(st + j));
+      }
+      flip ^= 1;
+      prev_row = cur_row;
+      have_prev = true;
+    }
+    HIPCHK(hipGetLastError());
+    // winners of iterations (off-1 .. off+c-2) are now in fin[0..c-1]
+    if (trace_index || trace_diff) {
+      HIPCHK(hipMemcpyAsync(hfin.data(), fin, sizeof(uint64_t) * 2 * (size_t)c, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      for (int64_t j = 0; j < c; j++) {
+        int64_t it = off + j - 1;
+        if (it < 0) continue;
+        for (int k = 0; k < knn; k++) {
+          int32_t idx; float df;
+          decode_key(hfin[(size_t)(2 * j + k)], knn == 2, &idx, &df);
+          if (trace_index) trace_index[it * knn + k] = idx;
+          if (trace_diff) trace_diff[it * knn + k] = df;
+        }
+      }
+    }
+    HIPCHK(hipMemcpyAsync(st, st + c, sizeof(LvqStep), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    (void)pending_trace;
+  }
+  // flush: apply the last iteration's correction; its winners land in fin[0]
+  {
+    LaunchTimer t(e, KID_LVQ_ONLINE_STEP);
+    hipLaunchKernelGGL(k_lvq_online_step, dim3((unsigned)nblk), dim3(256), 0, e->stream, cb->v, ds->d_rows,
+                       (const int32_t *)cb->d_labels, cb->d_talpha, prev_row, prev_row, 1, 0, knn,
+                       (const uint64_t *)part[flip], nblk, part[flip ^ 1], fin, (const LvqStep *)st);
+  }
+  HIPCHK(hipGetLastError());
+  if (trace_index || trace_diff) {
+    HIPCHK(hipMemcpyAsync(hfin.data(), fin, sizeof(uint64_t) * 2, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int64_t it = p->count - 1;
+    for (int k = 0; k < knn; k++) {
+      int32_t idx; float df;
+      decode_key(hfin[(size_t)k], knn == 2, &idx, &df);
+      if (trace_index) trace_index[it * knn + k] = idx;
+      if (trace_diff) trace_diff[it * knn + k] = df;
+    }
+  }
+  if (p->kind == SOMHIP_OLVQ1)
+    HIPCHK(hipMemcpyAsync(talpha, cb->d_talpha, sizeof(float) * (size_t)cb->v.n, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}

@@ -1,0 +1,204 @@
+"""Python host mirror of the engine's C ABI (include/somhip.h): thin objects over ctypes,
+numpy in / numpy out.  Used by the parity tests and bench.py; the command-line tools are
+C (som_lvq_pak_amd/host/).  Everything here runs on the GPU through libsomhip.so -- there
+is no CPU path."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import LvqParams, SomParams, check
+
+TOPOL_HEXA, TOPOL_RECT, TOPOL_LVQ = 3, 4, 2
+NEIGH_BUBBLE, NEIGH_GAUSSIAN = 1, 2
+ALPHA_LINEAR, ALPHA_INVERSE_T = 1, 2
+LVQ1, OLVQ1, LVQ2, LVQ3 = 1, 2, 3, 4
+TIE_FIRST, TIE_KNN = 0, 1
+
+
+def _p(a, typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+def _arr(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+class Engine:
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.somhip_engine_create(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.somhip_engine_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        check(self.lib.somhip_engine_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.somhip_engine_stream(self.h)
+
+    # --- timing table (HIP events on the engine's stream) ---
+    def timing(self, on=True):
+        check(self.lib.somhip_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        check(self.lib.somhip_timing_reset(self.h))
+
+    def timing_table(self):
+        out = {}
+        for i in range(self.lib.somhip_kernel_count()):
+            n = C.c_int64(0)
+            ms = C.c_double(0)
+            check(self.lib.somhip_timing_get(self.h, i, C.byref(n), C.byref(ms)))
+            out[self.lib.somhip_kernel_name(i).decode()] = (n.value, ms.value)
+        return out
+
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        check(self.lib.somhip_device_alloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def device_free(self, p):
+        check(self.lib.somhip_device_free(self.h, p))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Codebook:
+    """Device mirror of the `codes` list (reference lvq_pak.h:89-113)."""
+
+    def __init__(self, engine, rows, topol=TOPOL_LVQ, neigh=0, xdim=0, ydim=0, labels=None,
+                 row_offset=0, n_global=None):
+        self.e = engine
+        rows = _arr(rows, np.float32)
+        self.n, self.dim = rows.shape
+        labels = _arr(labels, np.int32)
+        self.labels = labels
+        self.topol, self.neigh, self.xdim, self.ydim = topol, neigh, xdim, ydim
+        self.row_offset = row_offset
+        self.n_global = self.n if n_global is None else n_global
+        h = C.c_void_p()
+        check(engine.lib.somhip_codebook_create(engine.h, _p(rows, _lib.c_float_p), _p(labels, _lib.c_i32_p),
+                                                self.n, self.dim, topol, neigh, xdim, ydim, row_offset,
+                                                self.n_global, C.byref(h)))
+        self.h = h
+
+    def download(self):
+        out = np.empty((self.n, self.dim), dtype=np.float32)
+        check(self.e.lib.somhip_codebook_download(self.h, _p(out, _lib.c_float_p)))
+        return out
+
+    def upload(self, rows):
+        rows = _arr(rows, np.float32)
+        assert rows.shape == (self.n, self.dim)
+        check(self.e.lib.somhip_codebook_upload(self.h, _p(rows, _lib.c_float_p)))
+
+    def close(self):
+        if self.h:
+            self.e.lib.somhip_codebook_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Dataset:
+    """Device mirror of the `data` list (one -buffer worth of rows)."""
+
+    def __init__(self, engine, rows=None, mask=None, labels=None, weight=None, fixed_xy=None,
+                 device_ptr=None, n=None, dim=None):
+        self.e = engine
+        h = C.c_void_p()
+        if device_ptr is not None:
+            self.n, self.dim = n, dim
+            check(engine.lib.somhip_dataset_wrap_device(engine.h, C.c_void_p(device_ptr), n, dim, C.byref(h)))
+        else:
+            rows = _arr(rows, np.float32)
+            self.n, self.dim = rows.shape
+            mask = _arr(mask, np.uint8)
+            labels = _arr(labels, np.int32)
+            weight = _arr(weight, np.int16)
+            fixed_xy = _arr(fixed_xy, np.int16)
+            check(engine.lib.somhip_dataset_create(engine.h, _p(rows, _lib.c_float_p), self.n, self.dim,
+                                                   _p(mask, _lib.c_u8_p), _p(labels, _lib.c_i32_p),
+                                                   _p(weight, _lib.c_i16_p), _p(fixed_xy, _lib.c_i16_p),
+                                                   C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.e.lib.somhip_dataset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def find_winners(cb, ds, first=0, count=None, knn=1, tie=TIE_FIRST):
+    """WINNER_FUNCTION over data rows [first, first+count): (index, diff, ret)."""
+    count = ds.n if count is None else count
+    idx = np.empty((count, knn), dtype=np.int32)
+    diff = np.empty((count, knn), dtype=np.float32)
+    ret = np.empty(count, dtype=np.int32)
+    check(cb.e.lib.somhip_find_winners(cb.h, ds.h, first, count, knn, tie, _p(idx, _lib.c_i32_p),
+                                       _p(diff, _lib.c_float_p), _p(ret, _lib.c_i32_p)))
+    return idx, diff, ret
+
+
+def som_train(cb, ds, length, alpha, radius, alpha_type=ALPHA_LINEAR, use_fixed=0, use_weights=0,
+              batch=1, start_iter=0, count=None, data_first=None, trace=True):
+    """som_training (reference som_rout.c:556); returns (trace_index, trace_diff)."""
+    count = length - start_iter if count is None else count
+    data_first = start_iter % ds.n if data_first is None else data_first
+    p = SomParams(length, alpha, radius, alpha_type, use_fixed, use_weights, batch, start_iter, count,
+                  data_first)
+    ti = np.empty(count, dtype=np.int32) if trace else None
+    td = np.empty(count, dtype=np.float32) if trace else None
+    check(cb.e.lib.somhip_som_train(cb.h, ds.h, C.byref(p), _p(ti, _lib.c_i32_p), _p(td, _lib.c_float_p)))
+    return ti, td
+
+
+def lvq_train(cb, ds, kind, length, alpha, alpha_type=ALPHA_LINEAR, winlen=0.0, epsilon=0.0,
+              talpha=None, start_iter=0, count=None, data_first=None, trace=True):
+    """lvq1/olvq1/lvq2/lvq3_training (reference lvq_rout.c:498-916)."""
+    count = length - start_iter if count is None else count
+    data_first = start_iter % ds.n if data_first is None else data_first
+    knn = 2 if kind in (LVQ2, LVQ3) else 1
+    p = LvqParams(kind, length, alpha, alpha_type, winlen, epsilon, start_iter, count, data_first)
+    if kind == OLVQ1:
+        talpha = (np.full(cb.n, alpha, dtype=np.float32) if talpha is None
+                  else np.ascontiguousarray(talpha, dtype=np.float32).copy())
+    ti = np.empty(count * knn, dtype=np.int32) if trace else None
+    td = np.empty(count * knn, dtype=np.float32) if trace else None
+    check(cb.e.lib.somhip_lvq_train(cb.h, ds.h, C.byref(p), _p(talpha, _lib.c_float_p),
+                                    _p(ti, _lib.c_i32_p), _p(td, _lib.c_float_p)))
+    return talpha, ti, td
+
+
+def qerror_sum(diff, ret=None):
+    """find_qerror's accumulation (reference som_rout.c:698-715): a float32 running sum of
+    double square roots in data order -- O(n) host work on the winners the GPU returned."""
+    q = np.float32(0.0)
+    d = np.asarray(diff, dtype=np.float32).reshape(-1)
+    for i in range(d.shape[0]):
+        if ret is not None and not ret[i]:
+            continue
+        q = np.float32(np.float64(q) + np.sqrt(np.float64(d[i])))
+    return q

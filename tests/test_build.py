@@ -1,0 +1,76 @@
+"""CPU-side checks of the product library: it builds for gfx950, exports every symbol
+include/somhip.h declares, fails loudly without a GPU (no CPU fallback), and the exact
+arithmetic chains contain no fused multiply-add."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def built():
+    lib = os.path.join(ROOT, "som_lvq_pak_amd", "libsomhip.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", ROOT, "lib"])
+    return lib
+
+
+def test_header_symbols_exported(built):
+    from som_lvq_pak_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "somhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(somhip_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libsomhip.so does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.somhip_version() == 1
+
+
+def test_no_cpu_fallback(built):
+    """without a GPU the engine must refuse, not silently compute on the host"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from som_lvq_pak_amd import engine as E
+    with pytest.raises(Exception, match="no HIP device|no CPU path|hip"):
+        E.Engine(0)
+
+
+def test_product_never_touches_oracle():
+    """nothing under som_lvq_pak_amd/ (the product) may import or link oracle/"""
+    pkg = os.path.join(ROOT, "som_lvq_pak_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hpp", ".hip", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"(^|\s)(from|import)\s+oracle\b", txt), f
+                assert "liboracle" not in txt and "oracle/_ref" not in txt and "ref_harness" not in txt, f
+
+
+def test_exact_kernels_have_no_fma(built, tmp_path):
+    """distance = fp32 sub, mul, add; update = sub, mul, add -- three roundings each
+    (reference lvq_pak.c:70-71, 348-349).  A contracted v_fma/v_fmac in those kernels would
+    change results, so look at the gfx950 ISA.  (Kernels that divide or call exp legitimately
+    contain fma inside the division / exp expansions and are checked for parity on the GPU.)"""
+    s = os.path.join(str(tmp_path), "k.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                           "-ffp-contract=off", "--cuda-device-only", "-S", "-o", s,
+                           os.path.join(ROOT, "som_lvq_pak_amd", "csrc", "somhip.hip")])
+    txt = open(s).read()
+    bodies = dict(re.findall(r"^(_ZN6somhip\w+):.*?\n(.*?)s_endpgm", txt, flags=re.S | re.M))
+    checked = 0
+    for name, body in bodies.items():
+        exact = ("k_scan_exact" in name or "k_scan_masked" in name
+                 or "k_som_update_runILi16ELb0" in name or "k_som_online_stepILb0" in name)
+        if not exact:
+            continue
+        checked += 1
+        bad = re.findall(r"\bv_(?:pk_)?(?:fma|fmac|mac|mad)_f32\b.*", body)
+        assert not bad, (name, bad[:3])
+        assert re.search(r"v_(pk_)?mul_f32", body) and re.search(r"v_(pk_)?add_f32", body)
+    assert checked >= 6

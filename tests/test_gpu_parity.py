@@ -1,0 +1,290 @@
+"""Parity of the HIP path (through the C ABI, libsomhip.so) with the oracle and with the
+fixtures the real reference produced.  Bit-exact: indices equal, fp32 values compared as
+bit patterns.  Needs an MI355X:  pytest -m gpu."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_trace, read_cod, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from som_lvq_pak_amd import engine as E
+    e = E.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def E():
+    from som_lvq_pak_amd import engine
+    return engine
+
+
+# --------------------------------------------------------------------------- layout
+@pytest.mark.parametrize("n,d", [(1, 1), (63, 3), (64, 4), (65, 5), (200, 20), (1000, 130)])
+def test_codebook_roundtrip(eng, E, n, d):
+    rs = np.random.RandomState(n * 7 + d)
+    rows = rs.standard_normal((n, d)).astype(np.float32)
+    cb = E.Codebook(eng, rows)
+    assert np.array_equal(bits(cb.download()), bits(rows))
+    rows2 = rows[::-1].copy()
+    cb.upload(rows2)
+    assert np.array_equal(bits(cb.download()), bits(rows2))
+    cb.close()
+
+
+# --------------------------------------------------------------------------- winner scans
+@pytest.mark.parametrize("n,d,m", [(5, 3, 7), (96, 5, 333), (200, 20, 1962), (1030, 130, 77), (4096, 64, 100)])
+def test_find_winner_euc_random(eng, E, oracle, n, d, m):
+    x, _ = synth(n + d, m, d)
+    rs = np.random.RandomState(n)
+    codes = (x[rs.randint(0, m, n)] + 0.25 * rs.standard_normal((n, d))).astype(np.float32)
+    cb, ds = E.Codebook(eng, codes), E.Dataset(eng, x)
+    gi, gd, gr = E.find_winners(cb, ds)
+    oi, od, _ = oracle.winners(codes, x)
+    assert np.array_equal(gi, oi)
+    assert np.array_equal(bits(gd), bits(od))
+    assert (gr == 1).all()
+    # sub-range with wrap-around start
+    gi2, gd2, _ = E.find_winners(cb, ds, first=m - 3, count=10)
+    want = np.concatenate([oi[m - 3:], oi[:7]])
+    assert np.array_equal(gi2, want)
+
+
+@pytest.mark.parametrize("knn", [1, 2, 5])
+def test_knn_ties_golden(eng, E, exdata, knn):
+    """duplicated rows force exact ties; expected values come from the real reference."""
+    ci, e2 = exdata["lvq_init"], exdata["ex2"]
+    cbrows = np.concatenate([ci.points[:40], ci.points[:40]], axis=0)
+    cb, ds = E.Codebook(eng, cbrows), E.Dataset(eng, e2.points[:300])
+    g = load_trace("knn_ties_%d" % knn)
+    gi, gd, gr = E.find_winners(cb, ds, knn=knn, tie=E.TIE_KNN)
+    assert np.array_equal(gi, g["index"])
+    assert np.array_equal(bits(gd), bits(g["diff"]))
+    g = load_trace("euc_ties")
+    gi, gd, _ = E.find_winners(cb, ds, knn=1, tie=E.TIE_FIRST)
+    assert np.array_equal(gi, g["index"]) and np.array_equal(bits(gd), bits(g["diff"]))
+
+
+@pytest.mark.parametrize("knn", [2, 3, 8])
+def test_knn_random(eng, E, oracle, knn):
+    x, _ = synth(77, 500, 24)
+    codes = x[:300:2] + 0.5
+    cb, ds = E.Codebook(eng, codes), E.Dataset(eng, x)
+    gi, gd, _ = E.find_winners(cb, ds, knn=knn, tie=E.TIE_KNN)
+    oi, od, _ = oracle.winners(codes, x, knn=knn, use_knn_fn=True)
+    assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od))
+
+
+def test_masked_winners(eng, E, oracle):
+    rs = np.random.RandomState(5)
+    x, _ = synth(6, 120, 9)
+    codes = x[:25] + 0.1
+    mask = (rs.rand(120, 9) < 0.3).astype(np.uint8)
+    mask[3] = 1
+    cb, ds = E.Codebook(eng, codes), E.Dataset(eng, x, mask=mask)
+    gi, gd, gr = E.find_winners(cb, ds)
+    oi, od, orr = oracle.winners(codes, x, mask=mask)
+    assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od)) and np.array_equal(gr, orr)
+    assert gr[3] == 0 and gi[3, 0] == -2
+
+
+def test_qerror_golden(eng, E, exdata):
+    """qerror = find_qerror (som_rout.c:678): GPU winners + the reference's fp32 running sum."""
+    g = load_trace("som_ex_hexa_bubble_linear")
+    cb, ds = E.Codebook(eng, g["codes"], E.TOPOL_HEXA, E.NEIGH_BUBBLE, 12, 8), E.Dataset(eng, exdata["ex"].points)
+    gi, gd, gr = E.find_winners(cb, ds)
+    assert np.array_equal(gi[:, 0], g["q_index"])
+    assert np.array_equal(bits(gd[:, 0]), bits(g["q_diff"]))
+    assert E.qerror_sum(gd, gr) == g["qerror_sum"]
+    fin = read_cod("somexample.cod")
+    cb2 = E.Codebook(eng, fin.points, E.TOPOL_HEXA, E.NEIGH_BUBBLE, 12, 8)
+    _, gd2, gr2 = E.find_winners(cb2, ds)
+    assert "%f" % float(E.qerror_sum(gd2, gr2) / np.float32(3840)) == "3.571006"
+
+
+# --------------------------------------------------------------------------- som_training, online
+TOPOL = {"hexa": 3, "rect": 4}
+NEIGH = {"bubble": 1, "gaussian": 2}
+
+
+@pytest.mark.parametrize("topol", ["hexa", "rect"])
+@pytest.mark.parametrize("neigh", ["bubble", "gaussian"])
+def test_som_online_golden(eng, E, exdata, topol, neigh):
+    g = load_trace("som_ex_%s_%s_linear" % (topol, neigh))
+    ini = read_cod("som_init_%s_%s.cod" % (topol, neigh))
+    cb = E.Codebook(eng, ini.points, TOPOL[topol], NEIGH[neigh], 12, 8)
+    ds = E.Dataset(eng, exdata["ex"].points)
+    ti, td = E.som_train(cb, ds, 5000, 0.05, 10.0)
+    assert np.array_equal(ti, g["trace_index"])
+    assert np.array_equal(bits(td), bits(g["trace_diff"]))
+    assert np.array_equal(bits(cb.download()), bits(g["codes"]))
+
+
+def test_som_online_inverse_t_and_segments(eng, E, exdata):
+    g = load_trace("som_ex_hexa_bubble_inverse_t")
+    ini = read_cod("som_init_hexa_bubble.cod")
+    cb = E.Codebook(eng, ini.points, 3, 1, 12, 8)
+    ds = E.Dataset(eng, exdata["ex"].points)
+    # the same schedule run in three pieces (what -snapinterval / -buffer need)
+    t1, _ = E.som_train(cb, ds, 5000, 0.05, 10.0, alpha_type=2, start_iter=0, count=1234)
+    t2, _ = E.som_train(cb, ds, 5000, 0.05, 10.0, alpha_type=2, start_iter=1234, count=2766)
+    t3, _ = E.som_train(cb, ds, 5000, 0.05, 10.0, alpha_type=2, start_iter=4000, count=1000)
+    assert np.array_equal(np.concatenate([t1, t2, t3]), g["trace_index"])
+    assert np.array_equal(bits(cb.download()), bits(g["codes"]))
+
+
+@pytest.mark.parametrize("neigh", [1, 2])
+def test_som_online_masks_weights_fixed(eng, E, neigh):
+    g = load_trace("som_masked_%d" % neigh)
+    cb = E.Codebook(eng, g["init"], 3, neigh, 7, 5)
+    ds = E.Dataset(eng, g["x"], mask=g["mask"], weight=g["weight"], fixed_xy=g["fixed"])
+    ti, td = E.som_train(cb, ds, 1500, 0.08, 4.0, use_fixed=1, use_weights=1)
+    assert np.array_equal(ti, g["trace_index"])
+    assert np.array_equal(bits(td), bits(g["trace_diff"]))
+    assert np.array_equal(bits(cb.download()), bits(g["codes"]))
+
+
+@pytest.mark.parametrize("topol,neigh", [(3, 1), (4, 2)])
+def test_som_online_synthetic_midsize(eng, E, oracle, topol, neigh):
+    g = load_trace("som_synth_%d_%d" % (topol, neigh))
+    x, _ = synth(21, 4000, 48, k=8)
+    ini = oracle.randinit(x, 24, 16, 5)
+    cb, ds = E.Codebook(eng, ini, topol, neigh, 24, 16), E.Dataset(eng, x)
+    ti, td = E.som_train(cb, ds, 6000, 0.05, 8.0)
+    assert np.array_equal(ti, g["trace_index"])
+    assert hashlib.sha256(td.tobytes()).hexdigest() == str(g["trace_diff_sha"])
+    assert hashlib.sha256(cb.download().tobytes()).hexdigest() == str(g["codes_sha"])
+
+
+# --------------------------------------------------------------------------- som_training, mini-batch
+@pytest.mark.parametrize("batch", [2, 16, 100, 4096])
+@pytest.mark.parametrize("topol,neigh", [(3, 1), (4, 2)])
+def test_som_minibatch_vs_batch_oracle(eng, E, oracle, batch, topol, neigh):
+    x, _ = synth(31, 700, 20)
+    ini = oracle.randinit(x, 10, 9, 4)
+    length = 1500                                  # wraps the data set twice
+    oc, oi, od = oracle.som_train(ini, 10, 9, topol, neigh, x, length, 0.07, 5.0, batch=batch)
+    cb, ds = E.Codebook(eng, ini, topol, neigh, 10, 9), E.Dataset(eng, x)
+    ti, td = E.som_train(cb, ds, length, 0.07, 5.0, batch=batch)
+    assert np.array_equal(ti, oi)
+    assert np.array_equal(bits(td), bits(od))
+    assert np.array_equal(bits(cb.download()), bits(oc))
+
+
+def test_som_minibatch_masks_weights_fixed(eng, E, oracle):
+    g = load_trace("som_masked_1")
+    oc, oi, od = oracle.som_train(g["init"], 7, 5, 3, 1, g["x"], 1500, 0.08, 4.0, weight=g["weight"],
+                                  fixed_xy=g["fixed"], mask=g["mask"], fixed_on=1, weights_on=1, batch=32)
+    cb = E.Codebook(eng, g["init"], 3, 1, 7, 5)
+    ds = E.Dataset(eng, g["x"], mask=g["mask"], weight=g["weight"], fixed_xy=g["fixed"])
+    ti, td = E.som_train(cb, ds, 1500, 0.08, 4.0, use_fixed=1, use_weights=1, batch=32)
+    assert np.array_equal(ti, oi) and np.array_equal(bits(td), bits(od))
+    assert np.array_equal(bits(cb.download()), bits(oc))
+
+
+def test_som_row_sharded_two_phase(eng, E, oracle):
+    """The multi-GPU decomposition on one GPU: two row shards, element-wise MIN of their
+    packed keys (what the RCCL all-reduce does), each shard updating only its own rows --
+    must equal the unsharded mini-batch run bit for bit."""
+    from som_lvq_pak_amd._lib import SomParams
+    x, _ = synth(41, 900, 16)
+    xdim, ydim, B, length = 16, 12, 64, 1280
+    ini = oracle.randinit(x, xdim, ydim, 8)
+    oc, oi, _ = oracle.som_train(ini, xdim, ydim, 3, 1, x, length, 0.05, 6.0, batch=B)
+    n = xdim * ydim
+    cut = 5 * xdim + 3                                       # deliberately not on a map-row edge
+    shards = [E.Codebook(eng, ini[:cut], 3, 1, xdim, ydim, row_offset=0, n_global=n),
+              E.Codebook(eng, ini[cut:], 3, 1, xdim, ydim, row_offset=cut, n_global=n)]
+    ds = E.Dataset(eng, x)
+    lib = eng.lib
+    kb = [eng.device_alloc(8 * B) for _ in range(3)]
+    hk = [np.empty(B, dtype=np.uint64) for _ in range(2)]
+    p = SomParams(length, 0.05, 6.0, 1, 0, 0, B, 0, length, 0)
+    got_idx = []
+    for it0 in range(0, length, B):
+        first = it0 % ds.n
+        for s in range(2):
+            assert lib.somhip_batch_winner_keys(shards[s].h, ds.h, first, B, kb[s]) == 0
+            assert lib.somhip_copy_to_host(eng.h, hk[s].ctypes.data_as(C.c_void_p), kb[s], 8 * B) == 0
+        merged = np.minimum(hk[0], hk[1])
+        got_idx.append((merged & np.uint64(0xFFFFFFFF)).astype(np.int64))
+        assert lib.somhip_copy_to_device(eng.h, kb[2], merged.ctypes.data_as(C.c_void_p), 8 * B) == 0
+        for s in range(2):
+            assert lib.somhip_som_batch_update(shards[s].h, ds.h, C.byref(p), it0, B, first, kb[2]) == 0
+    eng.sync()
+    assert np.array_equal(np.concatenate(got_idx), oi)
+    got = np.concatenate([shards[0].download(), shards[1].download()], axis=0)
+    assert np.array_equal(bits(got), bits(oc))
+    for k in kb:
+        eng.device_free(k)
+
+
+# --------------------------------------------------------------------------- lvq*_training
+LVQ_CASES = [("lvq1", 1, {}), ("olvq1", 2, {}), ("lvq2", 3, {"winlen": 0.3}),
+             ("lvq3", 4, {"winlen": 0.3, "epsilon": 0.1}), ("lvq1_invt", 1, {"alpha_type": 2})]
+
+
+@pytest.mark.parametrize("tag,kind,kw", LVQ_CASES)
+def test_lvq_golden(eng, E, exdata, tag, kind, kw):
+    from som_lvq_pak_amd import textio
+    g = load_trace("lvq_ex1_%s" % tag)
+    ci, e1, e2 = exdata["lvq_init"], exdata["ex1"], exdata["ex2"]
+    cb = E.Codebook(eng, ci.points, labels=ci.first_label)
+    ds = E.Dataset(eng, e1.points, labels=e1.first_label)
+    tal, ti, td = E.lvq_train(cb, ds, kind, 5000, 0.05, **kw)
+    assert np.array_equal(ti, g["trace_index"])
+    assert np.array_equal(bits(td), bits(g["trace_diff"]))
+    codes = cb.download()
+    assert np.array_equal(bits(codes), bits(g["codes"]))
+    if kind == 2:
+        assert [textio.fmt_g(a) for a in tal] == list(g["lra"])
+    ds2 = E.Dataset(eng, e2.points)
+    wi, _, _ = E.find_winners(cb, ds2)
+    assert int((ci.first_label[wi[:, 0]] == e2.first_label).sum()) == int(g["correct_on_ex2"])
+
+
+@pytest.mark.parametrize("kind", [1, 2, 3, 4])
+def test_lvq_random_vs_oracle_and_segments(eng, E, oracle, kind):
+    x, lab = synth(400 + kind, 640, 33, k=5, spread=2.0)
+    rs = np.random.RandomState(kind)
+    pick = rs.choice(640, 300, replace=False)
+    codes, clab = x[pick].copy(), lab[pick].copy()
+    kw = {"winlen": 0.25} if kind >= 3 else {}
+    if kind == 4:
+        kw["epsilon"] = 0.2
+    oc, ol, oi, od = oracle.lvq_train(kind, codes, clab, x, lab, 2000, 0.1, **kw)
+    cb = E.Codebook(eng, codes, labels=clab)
+    ds = E.Dataset(eng, x, labels=lab)
+    tal, t1, d1 = E.lvq_train(cb, ds, kind, 2000, 0.1, count=777, **kw)
+    tal, t2, d2 = E.lvq_train(cb, ds, kind, 2000, 0.1, start_iter=777, talpha=tal, **kw)
+    assert np.array_equal(np.concatenate([t1, t2]), oi)
+    assert np.array_equal(bits(np.concatenate([d1, d2])), bits(od))
+    assert np.array_equal(bits(cb.download()), bits(oc))
+    if kind == 2:
+        assert np.array_equal(bits(tal), bits(ol))
+
+
+# --------------------------------------------------------------------------- error behaviour
+def test_errors(eng, E):
+    rows = np.zeros((4, 3), dtype=np.float32)
+    cb = E.Codebook(eng, rows, 3, 1, 2, 2)
+    ds = E.Dataset(eng, np.zeros((5, 4), dtype=np.float32))
+    with pytest.raises(Exception, match="code dimension"):
+        E.som_train(cb, ds, 10, 0.1, 1.0)
+    cb2 = E.Codebook(eng, rows)           # not a map
+    ds2 = E.Dataset(eng, np.zeros((5, 3), dtype=np.float32))
+    with pytest.raises(Exception, match="SOM parameters"):
+        E.som_train(cb2, ds2, 10, 0.1, 1.0)
+    with pytest.raises(Exception, match="labels"):
+        E.lvq_train(cb2, ds2, 1, 10, 0.1)
