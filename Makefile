@@ -4,7 +4,10 @@
 #   make oracle  -> oracle/liboracle.so (+ oracle/_ref when /root/reference is present)
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
-HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-result
+# -fno-slp-vectorize: hipcc otherwise packs the scan's scalar fp32 ops into v_pk_* with
+# SGPR shuffles; measured 17 % slower on MI355X (profiles/r01_notes.md)
+EXTRA    ?=
+HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-result $(EXTRA)
 CSRC      = som_lvq_pak_amd/csrc
 LIB       = som_lvq_pak_amd/libsomhip.so
 

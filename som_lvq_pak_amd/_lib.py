@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsomhip.so")
+LIB_PATH = os.environ.get("SOMHIP_LIB", os.path.join(HERE, "libsomhip.so"))   # override: A/B builds
 
 c_float_p = C.POINTER(C.c_float)
 c_i32_p = C.POINTER(C.c_int32)

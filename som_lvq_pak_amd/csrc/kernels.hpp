@@ -106,7 +106,8 @@ struct StepScalars {
   float alpha;     // talp after schedule (+ weights), som_rout.c:617-624
   float thresh;    // bubble: largest lattice_sq value still inside the radius; gaussian: trad
   int32_t fixed;   // >= 0: unit index from the sample's fixed point (som_rout.c:628-632)
-  int32_t skip;    // 1: every component masked -> no search, no update (som_rout.c:635-640)
+  int32_t reach;   // >= 0: how many lattice rows the neighbourhood can span (conservative);
+                   // -1: every component masked -> no search, no update (som_rout.c:635-640)
 };
 
 // =====================================================================================
@@ -340,86 +341,160 @@ __global__ __launch_bounds__(256) void k_scan_masked(CbView cb, const float *__r
 }
 
 // =====================================================================================
+// K4a: winners of a run -> lattice coordinates.  bxy[b] = (bx, by) of iteration b's
+// best-matching unit (som_rout.c:641-642), from its key or its fixed point
+// (som_rout.c:628-632); bx = -1 when the iteration teaches nothing (skipped sample, or
+// no row beat FLT_MAX).
+// =====================================================================================
+__global__ void k_decode_winners(const uint64_t *__restrict__ keys, const StepScalars *__restrict__ sc,
+                                 int64_t count, int xdim, int2 *__restrict__ bxy) {
+  int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (b >= count) return;
+  const StepScalars s = sc[b];
+  int2 o = make_int2(-1, -1);
+  if (s.reach >= 0) {
+    uint32_t widx = 0xFFFFFFFFu;
+    if (s.fixed >= 0) widx = static_cast<uint32_t>(s.fixed);
+    else {
+      uint64_t k = keys[b];
+      if (static_cast<uint32_t>(k >> 32) < FLT_MAX_BITS) widx = static_cast<uint32_t>(k);
+    }
+    if (widx != 0xFFFFFFFFu) o = make_int2(static_cast<int>(widx % static_cast<uint32_t>(xdim)),
+                                           static_cast<int>(widx / static_cast<uint32_t>(xdim)));
+  }
+  bxy[b] = o;
+}
+
+// =====================================================================================
 // K4: in-order neighbourhood update of a run of `count` samples whose winners are known.
 //
 // bubble_adapt (som_rout.c:472-506) / gaussian_adapt (:511-549) + adapt_vector
 // (lvq_pak.c:339-351) for iterations batch_start .. batch_start+count-1, applied to
 // every code row in iteration order.  One lane = one code row, QW chunks (4*QW dims) of
 // it held in registers across the whole run, so each touched row is read and written
-// once per run whatever the batch size.  Lattice membership is decided per lane from
-// the winner's coordinates; x is read through wave-uniform loads.
+// once per run whatever the batch size.  A workgroup = 4 row groups x one slice of
+// 4*QW dims; the samples' slice is staged through LDS in tiles of TB samples (one
+// coalesced pass, shared by the 4 waves, read back as broadcasts).  Tiles and samples
+// whose neighbourhood cannot reach the workgroup's / wave's units are skipped on a
+// bounding-box test with the per-iteration reach computed on the host.
 // =====================================================================================
-template <int QW, bool GAUSS, bool MASKED>
+template <int QW, int TB, bool GAUSS, bool MASKED>
 __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *__restrict__ rows,
                                                         const uint8_t *__restrict__ mask,
                                                         int64_t n_rows, int64_t data_first,
                                                         int64_t count,
-                                                        const uint64_t *__restrict__ keys,
+                                                        const int2 *__restrict__ bxy,
                                                         const StepScalars *__restrict__ sc) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t g = blockIdx.x;
-  const int q0 = (blockIdx.y * 4 + wave) * QW;
-  if (q0 >= cb.d4) return;
+  __shared__ float4 xs[TB][QW];
+  __shared__ uint32_t ms[MASKED ? TB : 1][MASKED ? QW : 1];   // 4 mask bytes per chunk
+  __shared__ int s_bx[TB], s_by[TB], s_reach[TB], s_hit[TB];
+  __shared__ float s_alpha[TB], s_thr[TB];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  const int q0 = blockIdx.y * QW;
+  const uint32_t xdim = static_cast<uint32_t>(cb.xdim);
+  const bool wave_on = g < cb.ngroups;
   const int64_t row = g * WAVE + lane;
-  const int64_t grow = row + cb.row_offset;
-  const int tx = static_cast<int>(grow % cb.xdim), ty = static_cast<int>(grow / cb.xdim);
-  const bool live = row < cb.n;
+  const bool live = wave_on && row < cb.n;
+  const uint32_t grow = static_cast<uint32_t>(row + cb.row_offset);
+  const int tx = static_cast<int>(grow % xdim), ty = static_cast<int>(grow / xdim);
+
+  // unit rows (lattice y) this workgroup / this wave can touch
+  const int64_t blk_r0 = static_cast<int64_t>(blockIdx.x) * 4 * WAVE;
+  const int64_t blk_r1 = (blk_r0 + 4 * WAVE < cb.n ? blk_r0 + 4 * WAVE : cb.n) - 1;
+  const int blk_ty0 = static_cast<int>(static_cast<uint32_t>(blk_r0 + cb.row_offset) / xdim);
+  const int blk_ty1 = static_cast<int>(static_cast<uint32_t>(blk_r1 + cb.row_offset) / xdim);
+  int w_ty0 = 0, w_ty1 = -1;
+  if (wave_on) {
+    int64_t r0 = g * WAVE, r1 = (r0 + WAVE < cb.n ? r0 + WAVE : cb.n) - 1;
+    w_ty0 = static_cast<int>(static_cast<uint32_t>(r0 + cb.row_offset) / xdim);
+    w_ty1 = static_cast<int>(static_cast<uint32_t>(r1 + cb.row_offset) / xdim);
+  }
+  w_ty0 = __builtin_amdgcn_readfirstlane(w_ty0);
+  w_ty1 = __builtin_amdgcn_readfirstlane(w_ty1);
 
   float4 c[QW];
 #pragma unroll
   for (int j = 0; j < QW; j++)
-    c[j] = (q0 + j < cb.d4) ? *tile_ptr(cb, g, q0 + j, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    c[j] = (wave_on && q0 + j < cb.d4) ? *tile_ptr(cb, g, q0 + j, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
   bool dirty = false;
+  const bool vec = (cb.d & 3) == 0;
 
-  for (int64_t b = 0; b < count; b++) {
-    const StepScalars s = sc[b];
-    if (s.skip) continue;
-    int64_t widx;
-    if (s.fixed >= 0) widx = s.fixed;
-    else {
-      uint64_t k = keys[b];
-      if (static_cast<uint32_t>(k >> 32) >= FLT_MAX_BITS) continue;   // no winner
-      widx = static_cast<uint32_t>(k);
+  for (int64_t t0 = 0; t0 < count; t0 += TB) {
+    const int tb = static_cast<int>(count - t0 < TB ? count - t0 : TB);
+    // ---- phase 1: per-sample scalars + reach test against the workgroup's unit rows
+    int hit = 0;
+    if (tid < TB) {
+      int bx = -1, by = -1, reach = -1;
+      float al = 0.f, th = 0.f;
+      if (tid < tb) {
+        const int2 w = bxy[t0 + tid];
+        const StepScalars s = sc[t0 + tid];
+        bx = w.x; by = w.y; reach = s.reach; al = s.alpha; th = s.thresh;
+        hit = (bx >= 0) && (by + reach >= blk_ty0) && (by - reach <= blk_ty1);
+      }
+      s_bx[tid] = bx; s_by[tid] = by; s_reach[tid] = reach; s_alpha[tid] = al; s_thr[tid] = th;
+      s_hit[tid] = hit;
     }
-    const int bx = static_cast<int>(widx % cb.xdim), by = static_cast<int>(widx / cb.xdim);
-    const float lsq = lattice_sq(cb.topol, bx, by, tx, ty);
-    float a;
-    bool member;
-    if (GAUSS) { a = gaussian_alpha(lsq, s.thresh, s.alpha); member = live; }
-    else { a = s.alpha; member = live && (lsq <= s.thresh); }
-    if (!__any(member)) continue;
-    const int64_t r = (data_first + b) % n_rows;
-    const float4 *x4 = reinterpret_cast<const float4 *>(rows + r * cb.d);
-    if (member) {
-      dirty = true;
+    if (!__syncthreads_or(hit)) continue;      // nothing in this tile reaches us (uniform)
+    // ---- phase 2: the tile's slice of the samples -> LDS
+    for (int e = tid; e < TB * QW; e += 256) {
+      const int s = e / QW, j = e % QW, q = q0 + j;
+      if (s < tb && s_hit[s] && q < cb.d4) {
+        const int64_t r = (data_first + t0 + s) % n_rows;
+        const float *xr = rows + r * cb.d;
+        float4 x;
+        if (vec) x = reinterpret_cast<const float4 *>(xr)[q];
+        else {
+          x.x = q * 4 + 0 < cb.d ? xr[q * 4 + 0] : 0.f;
+          x.y = q * 4 + 1 < cb.d ? xr[q * 4 + 1] : 0.f;
+          x.z = q * 4 + 2 < cb.d ? xr[q * 4 + 2] : 0.f;
+          x.w = q * 4 + 3 < cb.d ? xr[q * 4 + 3] : 0.f;
+        }
+        xs[s][j] = x;
+        if (MASKED) {
+          const uint8_t *m = mask + r * cb.d;
+          uint32_t mm = 0;
 #pragma unroll
-      for (int j = 0; j < QW; j++) {
-        int q = q0 + j;
-        if (q < cb.d4) {
-          float4 x;
-          if ((cb.d & 3) == 0) x = x4[q];                 // wave-uniform
-          else {
-            const float *xr = rows + r * cb.d;
-            x.x = q * 4 + 0 < cb.d ? xr[q * 4 + 0] : 0.f;
-            x.y = q * 4 + 1 < cb.d ? xr[q * 4 + 1] : 0.f;
-            x.z = q * 4 + 2 < cb.d ? xr[q * 4 + 2] : 0.f;
-            x.w = q * 4 + 3 < cb.d ? xr[q * 4 + 3] : 0.f;
-          }
-          if (MASKED) {
-            const uint8_t *m = mask + r * cb.d + q * 4;
-            float4 n = adapt4(c[j], x, a);
-            if (q * 4 + 0 < cb.d && m[0] == 0) c[j].x = n.x;
-            if (q * 4 + 1 < cb.d && m[1] == 0) c[j].y = n.y;
-            if (q * 4 + 2 < cb.d && m[2] == 0) c[j].z = n.z;
-            if (q * 4 + 3 < cb.d && m[3] == 0) c[j].w = n.w;
-          } else {
-            float4 n = adapt4(c[j], x, a);
-            // padding dims stay 0: x pad = 0 and c pad = 0 give 0 + a*(0-0) = 0
-            c[j] = n;
+          for (int u = 0; u < 4; u++)
+            if (q * 4 + u >= cb.d || m[q * 4 + u] != 0) mm |= 1u << u;
+          ms[s][j] = mm;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: the tile's updates, in iteration order
+    if (wave_on) {
+      for (int s = 0; s < tb; s++) {
+        if (!s_hit[s]) continue;
+        const int bx = s_bx[s], by = s_by[s], reach = s_reach[s];
+        if (by + reach < w_ty0 || by - reach > w_ty1) continue;
+        const float lsq = lattice_sq(cb.topol, bx, by, tx, ty);
+        float a;
+        bool member;
+        if (GAUSS) { a = gaussian_alpha(lsq, s_thr[s], s_alpha[s]); member = live; }
+        else { a = s_alpha[s]; member = live && (lsq <= s_thr[s]); }
+        if (!__any(member)) continue;
+        if (member) {
+          dirty = true;
+#pragma unroll
+          for (int j = 0; j < QW; j++) {
+            const float4 n = adapt4(c[j], xs[s][j], a);
+            if (MASKED) {
+              const uint32_t mm = ms[s][j];
+              if (!(mm & 1u)) c[j].x = n.x;
+              if (!(mm & 2u)) c[j].y = n.y;
+              if (!(mm & 4u)) c[j].z = n.z;
+              if (!(mm & 8u)) c[j].w = n.w;
+            } else {
+              c[j] = n;      // padding dims: x pad = 0, c pad = 0 -> stays 0
+            }
           }
         }
       }
     }
+    __syncthreads();
   }
   if (dirty) {
 #pragma unroll
@@ -436,8 +511,10 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
 // twice, and written only where it changed.  The winner of iteration t is folded into
 // slot[t] with a 64-bit atomic min; the next launch (stream order) reads it.
 //   has_prev / has_cur select prologue (no update yet) and flush (no search left).
+// A wave streams its 64 rows U chunks (U KiB) at a time, all U loads issued before the
+// first use, so a CU with 4 such waves keeps 4*U KiB of HBM reads in flight.
 // =====================================================================================
-template <bool GAUSS, bool MASKED>
+template <bool GAUSS, bool MASKED, int U>
 __global__ __launch_bounds__(256) void k_som_online_step(CbView cb, const float *__restrict__ rows,
                                                          const uint8_t *__restrict__ mask,
                                                          int64_t prev_row, int64_t cur_row,
@@ -450,31 +527,32 @@ __global__ __launch_bounds__(256) void k_som_online_step(CbView cb, const float 
   const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave;
   if (g >= cb.ngroups) return;
   const int64_t row = g * WAVE + lane;
-  const int64_t grow = row + cb.row_offset;
+  const uint32_t grow = static_cast<uint32_t>(row + cb.row_offset);
+  const uint32_t xdim = static_cast<uint32_t>(cb.xdim);
   const bool live = row < cb.n;
 
   bool upd = false;
   float a = 0.0f;
   if (has_prev) {
     const StepScalars s = *prev_sc;
-    int64_t widx = -1;
-    if (!s.skip) {
-      if (s.fixed >= 0) widx = s.fixed;
+    uint32_t widx = 0xFFFFFFFFu;
+    if (s.reach >= 0) {
+      if (s.fixed >= 0) widx = static_cast<uint32_t>(s.fixed);
       else {
         uint64_t k = *prev_slot;
         if (static_cast<uint32_t>(k >> 32) < FLT_MAX_BITS) widx = static_cast<uint32_t>(k);
       }
     }
-    if (widx >= 0) {
-      const int tx = static_cast<int>(grow % cb.xdim), ty = static_cast<int>(grow / cb.xdim);
-      const int bx = static_cast<int>(widx % cb.xdim), by = static_cast<int>(widx / cb.xdim);
+    if (widx != 0xFFFFFFFFu) {
+      const int tx = static_cast<int>(grow % xdim), ty = static_cast<int>(grow / xdim);
+      const int bx = static_cast<int>(widx % xdim), by = static_cast<int>(widx / xdim);
       const float lsq = lattice_sq(cb.topol, bx, by, tx, ty);
       if (GAUSS) { a = gaussian_alpha(lsq, s.thresh, s.alpha); upd = live; }
       else { a = s.alpha; upd = live && (lsq <= s.thresh); }
     }
   }
   bool search = has_cur;
-  if (has_cur) { const StepScalars s = *cur_sc; if (s.skip || s.fixed >= 0) search = false; }
+  if (has_cur) { const StepScalars s = *cur_sc; if (s.reach < 0 || s.fixed >= 0) search = false; }
   const bool any_upd = __any(upd);
   if (!any_upd && !search) return;
 
@@ -485,54 +563,66 @@ __global__ __launch_bounds__(256) void k_som_online_step(CbView cb, const float 
   const bool vec = (cb.d & 3) == 0;
   float acc = 0.0f;
 
-  for (int q = 0; q < cb.d4; q++) {
-    float4 c = *tile_ptr(cb, g, q, lane);
-    if (any_upd) {
-      float4 x;
-      if (vec) x = reinterpret_cast<const float4 *>(xp)[q];
-      else {
-        x.x = q * 4 + 0 < cb.d ? xp[q * 4 + 0] : 0.f;
-        x.y = q * 4 + 1 < cb.d ? xp[q * 4 + 1] : 0.f;
-        x.z = q * 4 + 2 < cb.d ? xp[q * 4 + 2] : 0.f;
-        x.w = q * 4 + 3 < cb.d ? xp[q * 4 + 3] : 0.f;
-      }
-      if (upd) {
-        float4 n = adapt4(c, x, a);
-        if (MASKED) {
-          if (q * 4 + 0 < cb.d && mp[q * 4 + 0] == 0) c.x = n.x;
-          if (q * 4 + 1 < cb.d && mp[q * 4 + 1] == 0) c.y = n.y;
-          if (q * 4 + 2 < cb.d && mp[q * 4 + 2] == 0) c.z = n.z;
-          if (q * 4 + 3 < cb.d && mp[q * 4 + 3] == 0) c.w = n.w;
-        } else {
-          c = n;
-        }
-        *tile_ptr_w(cb, g, q, lane) = c;
-      }
+  for (int qb = 0; qb < cb.d4; qb += U) {
+    float4 cc[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      int q = qb + u < cb.d4 ? qb + u : cb.d4 - 1;
+      cc[u] = *tile_ptr(cb, g, q, lane);
     }
-    if (search) {
-      float4 x;
-      if (vec) x = reinterpret_cast<const float4 *>(xc)[q];
-      else {
-        x.x = q * 4 + 0 < cb.d ? xc[q * 4 + 0] : 0.f;
-        x.y = q * 4 + 1 < cb.d ? xc[q * 4 + 1] : 0.f;
-        x.z = q * 4 + 2 < cb.d ? xc[q * 4 + 2] : 0.f;
-        x.w = q * 4 + 3 < cb.d ? xc[q * 4 + 3] : 0.f;
-      }
-      if (MASKED) {
-        if (q * 4 + 0 < cb.d && mc[q * 4 + 0] == 0) acc = sq_acc(acc, c.x, x.x);
-        if (q * 4 + 1 < cb.d && mc[q * 4 + 1] == 0) acc = sq_acc(acc, c.y, x.y);
-        if (q * 4 + 2 < cb.d && mc[q * 4 + 2] == 0) acc = sq_acc(acc, c.z, x.z);
-        if (q * 4 + 3 < cb.d && mc[q * 4 + 3] == 0) acc = sq_acc(acc, c.w, x.w);
-      } else {
-        acc = sq_acc(acc, c.x, x.x);
-        acc = sq_acc(acc, c.y, x.y);
-        acc = sq_acc(acc, c.z, x.z);
-        acc = sq_acc(acc, c.w, x.w);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int q = qb + u;
+      if (q < cb.d4) {
+        float4 c = cc[u];
+        if (any_upd) {
+          float4 x;
+          if (vec) x = reinterpret_cast<const float4 *>(xp)[q];
+          else {
+            x.x = q * 4 + 0 < cb.d ? xp[q * 4 + 0] : 0.f;
+            x.y = q * 4 + 1 < cb.d ? xp[q * 4 + 1] : 0.f;
+            x.z = q * 4 + 2 < cb.d ? xp[q * 4 + 2] : 0.f;
+            x.w = q * 4 + 3 < cb.d ? xp[q * 4 + 3] : 0.f;
+          }
+          if (upd) {
+            float4 n = adapt4(c, x, a);
+            if (MASKED) {
+              if (q * 4 + 0 < cb.d && mp[q * 4 + 0] == 0) c.x = n.x;
+              if (q * 4 + 1 < cb.d && mp[q * 4 + 1] == 0) c.y = n.y;
+              if (q * 4 + 2 < cb.d && mp[q * 4 + 2] == 0) c.z = n.z;
+              if (q * 4 + 3 < cb.d && mp[q * 4 + 3] == 0) c.w = n.w;
+            } else {
+              c = n;
+            }
+            *tile_ptr_w(cb, g, q, lane) = c;
+          }
+        }
+        if (search) {
+          float4 x;
+          if (vec) x = reinterpret_cast<const float4 *>(xc)[q];
+          else {
+            x.x = q * 4 + 0 < cb.d ? xc[q * 4 + 0] : 0.f;
+            x.y = q * 4 + 1 < cb.d ? xc[q * 4 + 1] : 0.f;
+            x.z = q * 4 + 2 < cb.d ? xc[q * 4 + 2] : 0.f;
+            x.w = q * 4 + 3 < cb.d ? xc[q * 4 + 3] : 0.f;
+          }
+          if (MASKED) {
+            if (q * 4 + 0 < cb.d && mc[q * 4 + 0] == 0) acc = sq_acc(acc, c.x, x.x);
+            if (q * 4 + 1 < cb.d && mc[q * 4 + 1] == 0) acc = sq_acc(acc, c.y, x.y);
+            if (q * 4 + 2 < cb.d && mc[q * 4 + 2] == 0) acc = sq_acc(acc, c.z, x.z);
+            if (q * 4 + 3 < cb.d && mc[q * 4 + 3] == 0) acc = sq_acc(acc, c.w, x.w);
+          } else {
+            acc = sq_acc(acc, c.x, x.x);
+            acc = sq_acc(acc, c.y, x.y);
+            acc = sq_acc(acc, c.z, x.z);
+            acc = sq_acc(acc, c.w, x.w);
+          }
+        }
       }
     }
   }
   if (search) {
-    uint64_t k = live ? make_key(acc, static_cast<uint32_t>(grow)) : KEY_NONE;
+    uint64_t k = live ? make_key(acc, grow) : KEY_NONE;
     k = wave_min_u64(k);
     if (lane == 0)
       atomicMin(reinterpret_cast<unsigned long long *>(cur_slot), static_cast<unsigned long long>(k));

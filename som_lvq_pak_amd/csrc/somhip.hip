@@ -56,11 +56,12 @@ enum KernelId {
   KID_MERGE_TOPK,
   KID_SCAN_MASKED,
   KID_LAYOUT,
+  KID_DECODE,
   KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {
     "k_scan_exact", "k_som_update_run", "k_som_online_step", "k_lvq_online_step",
-    "k_pack_samples", "k_merge_topk", "k_scan_masked", "k_layout"};
+    "k_pack_samples", "k_merge_topk", "k_scan_masked", "k_layout", "k_decode_winners"};
 extern "C" int somhip_kernel_count(void) { return KID_COUNT; }
 extern "C" const char *somhip_kernel_name(int i) { return (i >= 0 && i < KID_COUNT) ? kKernelNames[i] : ""; }
 
@@ -507,24 +508,29 @@ static int som_scalars(const somhip_codebook *cb, const somhip_dataset *ds, cons
     s.alpha = talp;
     s.thresh = gauss ? trad : bubble_threshold(trad);
     s.fixed = -1;
-    s.skip = (!ds->all_masked.empty() && ds->all_masked[(size_t)r]) ? 1 : 0;
+    // lattice rows a neighbourhood of this radius can span: hexa rows are sqrt(0.75)
+    // apart (som_rout.c:451), rect rows 1 apart; +1 keeps it conservative
+    double reach = gauss ? 1e9 : (trad > 0.0f ? (double)trad / (cb->v.topol == SOMHIP_TOPOL_RECT ? 1.0 : 0.8660254037844386) + 1.0 : 1.0);
+    s.reach = reach > 1e6 ? 1000000 : (int32_t)reach;
+    if (!ds->all_masked.empty() && ds->all_masked[(size_t)r]) s.reach = -1;
     if (p->use_fixed && !ds->fixed_xy.empty() && ds->fixed_xy[(size_t)(2 * r)] >= 0) {
       int fx = ds->fixed_xy[(size_t)(2 * r)], fy = ds->fixed_xy[(size_t)(2 * r + 1)];
       s.fixed = fy * cb->v.xdim + fx;      // inverse of som_rout.c:641-642
-      s.skip = 0;
+      if (s.reach < 0) s.reach = reach > 1e6 ? 1000000 : (int32_t)reach;
     }
     out[j] = s;
   }
   return 0;
 }
 
+constexpr int ONLINE_U = 16;   // KiB of code rows a wave keeps in flight
 template <bool G, bool M>
 static void launch_online(somhip_engine *e, const somhip_codebook *cb, const somhip_dataset *ds,
                           int64_t prev_row, int64_t cur_row, int has_prev, int has_cur,
                           const uint64_t *prev_slot, uint64_t *cur_slot, const StepScalars *prev_sc,
                           const StepScalars *cur_sc) {
   LaunchTimer t(e, KID_SOM_ONLINE_STEP);
-  hipLaunchKernelGGL((k_som_online_step<G, M>), dim3((unsigned)((cb->v.ngroups + 3) / 4)), dim3(256), 0,
+  hipLaunchKernelGGL((k_som_online_step<G, M, ONLINE_U>), dim3((unsigned)((cb->v.ngroups + 3) / 4)), dim3(256), 0,
                      e->stream, cb->v, ds->d_rows, (const uint8_t *)ds->d_mask, prev_row, cur_row,
                      has_prev, has_cur, prev_slot, cur_slot, prev_sc, cur_sc);
 }
@@ -567,7 +573,7 @@ static int som_train_online(somhip_codebook *cb, somhip_dataset *ds, const somhi
         int32_t idx; float df;
         const StepScalars &s = hsc[(size_t)j + 1];
         if (s.fixed >= 0) { idx = -3; df = -1.0f; }
-        else if (s.skip) { idx = -2; df = -1.0f; }
+        else if (s.reach < 0) { idx = -2; df = -1.0f; }
         else decode_key(hslot[(size_t)j], false, &idx, &df);
         if (trace_index) trace_index[off + j] = idx;
         if (trace_diff) trace_diff[off + j] = df;
@@ -593,12 +599,20 @@ static int som_update_run(somhip_codebook *cb, somhip_dataset *ds, int64_t data_
                           const uint64_t *d_keys, const StepScalars *d_sc) {
   somhip_engine *e = cb->e;
   const bool G = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN, M = ds->d_mask != nullptr;
-  constexpr int QW = 16;
-  dim3 grid((unsigned)cb->v.ngroups, (unsigned)((cb->v.d4 + 4 * QW - 1) / (4 * QW)));
+  constexpr int QW = 16, TB = 64;
+  void *dbxy;
+  CHK(engine_scratch(e, 5, sizeof(int2) * (size_t)count, &dbxy));
+  {
+    LaunchTimer t(e, KID_DECODE);
+    hipLaunchKernelGGL(k_decode_winners, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream,
+                       d_keys, d_sc, count, cb->v.xdim, (int2 *)dbxy);
+  }
+  HIPCHK(hipGetLastError());
+  dim3 grid((unsigned)((cb->v.ngroups + 3) / 4), (unsigned)((cb->v.d4 + QW - 1) / QW));
   LaunchTimer t(e, KID_SOM_UPDATE_RUN);
 #define GO(GG, MM)                                                                                   \
-  hipLaunchKernelGGL((k_som_update_run<QW, GG, MM>), grid, dim3(256), 0, e->stream, cb->v, ds->d_rows, \
-                     (const uint8_t *)ds->d_mask, ds->n, data_first, count, d_keys, d_sc)
+  hipLaunchKernelGGL((k_som_update_run<QW, TB, GG, MM>), grid, dim3(256), 0, e->stream, cb->v, ds->d_rows, \
+                     (const uint8_t *)ds->d_mask, ds->n, data_first, count, (const int2 *)dbxy, d_sc)
   if (G && M) GO(true, true); else if (G) GO(true, false); else if (M) GO(false, true); else GO(false, false);
 #undef GO
   HIPCHK(hipGetLastError());
@@ -648,7 +662,7 @@ static int som_train_batched(somhip_codebook *cb, somhip_dataset *ds, const somh
       for (int64_t j = 0; j < c; j++) {
         int32_t idx; float df;
         if (hsc[(size_t)j].fixed >= 0) { idx = -3; df = -1.0f; }
-        else if (hsc[(size_t)j].skip) { idx = -2; df = -1.0f; }
+        else if (hsc[(size_t)j].reach < 0) { idx = -2; df = -1.0f; }
         else decode_key(hk[(size_t)j], false, &idx, &df);
         if (trace_index) trace_index[off + j] = idx;
         if (trace_diff) trace_diff[off + j] = df;
