@@ -15,7 +15,7 @@ LIB       = som_lvq_pak_amd/libsomhip.so
 all: lib oracle tools
 
 lib: $(LIB)
-$(LIB): $(CSRC)/somhip.hip $(CSRC)/kernels.hpp $(CSRC)/schedule.hpp include/somhip.h
+$(LIB): $(CSRC)/somhip.hip $(CSRC)/kernels.hpp $(CSRC)/schedule.hpp include/somhip.h Makefile
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/somhip.hip
 
 # device ISA of the kernels, for the no-FMA check (tests/test_build.py) and for reading

@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- training vectors/sec of the SOM hot path on MI355X.
+
+Workload (BASELINE.json configs[3], the configuration the metric is quoted on; it fits one
+GPU): `vsom` on a 256x256 hexagonal map with bubble neighbourhood, dim = 512 (codebook
+65 536 x 512 fp32 = 128 MiB), alpha 0.05 linear, radius 128 -> 1, synthetic 256-component
+Gaussian mixture generated on the device (no data sets / no network here).
+
+A "step" is one mini-batch of --batch vectors through the whole hot path: exact
+best-matching-unit search for every vector + the in-order neighbourhood update.  The K
+timed steps form one complete training run of K*batch vectors (the radius sweeps its whole
+range inside the timed region).  With --batch 1 the engine runs the reference's strictly
+online algorithm instead (bit-exact with the CPU reference, much slower).
+
+N > 1 (one process per GPU, torch.distributed/RCCL): the codebook is row-sharded, every
+rank scans its shard for the same batch, one all-reduce(MIN) of packed (distance, index)
+keys gives the global winners, each rank updates its own rows.  Total work is fixed as N
+grows -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_TFLOPS = 157.3     # MI355X fp32 matrix == fp32 vector FMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--xdim", type=int, default=256)
+    ap.add_argument("--ydim", type=int, default=256)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--alpha", type=float, default=0.05)
+    ap.add_argument("--radius", type=float, default=None)
+    ap.add_argument("--cpu-vectors", type=int, default=400,
+                    help="vectors the CPU reference trains on for cpu_baseline (0 = skip)")
+    ap.add_argument("--eval-vectors", type=int, default=8192)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from som_lvq_pak_amd import engine as E
+    from som_lvq_pak_amd._lib import SomParams
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (a.gpus, a.gpus))
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, K, W = a.batch, a.steps, a.warmup
+    xdim, ydim, d = a.xdim, a.ydim, a.dim
+    N = xdim * ydim
+    radius = a.radius if a.radius is not None else max(xdim, ydim) / 2.0
+    length = K * B
+
+    # ---- synthetic data, identical on every rank, resident in HBM before timing ----
+    g = torch.Generator(device=dev)
+    g.manual_seed(3456)
+    ncent = 256
+    centres = 4.0 * torch.randn(ncent, d, generator=g, device=dev)
+    nvec = (K + W) * B
+    assign = torch.randint(0, ncent, (nvec,), generator=g, device=dev)
+    data = centres[assign] + torch.randn(nvec, d, generator=g, device=dev)
+    data = data.contiguous()
+    lo, hi = data.min(0).values, data.max(0).values
+    init = (lo + (hi - lo) * torch.rand(N, d, generator=g, device=dev)).cpu().numpy()   # randinit-like
+    del centres, assign
+    torch.cuda.synchronize()
+
+    eng = E.Engine(local)
+    ds = E.Dataset(eng, device_ptr=data.data_ptr(), n=nvec, dim=d)
+    rows_per = (N + world - 1) // world
+    r0, r1 = rank * rows_per, min(N, (rank + 1) * rows_per)
+    cb = E.Codebook(eng, init[r0:r1], E.TOPOL_HEXA, E.NEIGH_BUBBLE, xdim, ydim, row_offset=r0, n_global=N)
+    lib = eng.lib
+    keys = torch.empty(max(B, a.eval_vectors), dtype=torch.int64, device=dev)
+
+    def step(it0, data_first, count, length_):
+        p = SomParams(length_, a.alpha, radius, E.ALPHA_LINEAR, 0, 0, max(B, 1), it0, count, data_first)
+        if world == 1:
+            E.check(lib.somhip_som_train(cb.h, ds.h, C.byref(p), None, None))
+            return
+        # two-phase: local shard winners -> all-reduce(MIN) of packed keys -> local update
+        E.check(lib.somhip_batch_winner_keys(cb.h, ds.h, data_first, count, C.c_void_p(keys.data_ptr())))
+        eng.sync()
+        kk = keys[:count]
+        # distance bits >= 0, so int64 order == uint64 order -- except the all-ones "no winner" key
+        kk.copy_(torch.where(kk < 0, torch.full_like(kk, 0x7FFFFFFFFFFFFFFF), kk))
+        dist.all_reduce(kk, op=dist.ReduceOp.MIN)
+        torch.cuda.current_stream().synchronize()
+        E.check(lib.somhip_som_batch_update(cb.h, ds.h, C.byref(p), it0, count, data_first,
+                                            C.c_void_p(keys.data_ptr())))
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup on the first W batches, then restore the initial codebook ----
+    for k in range(W):
+        step(k * B, k * B, B, max(W, 1) * B)
+    eng.sync()
+    cb.upload(init[r0:r1])
+
+    # ---- timed region: one complete training run of K*B vectors ----
+    eng.timing(True)
+    eng.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(K):
+        step(k * B, W * B + k * B, B, length)
+    barrier()
+    t1 = time.perf_counter()
+    eng.timing(False)
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    table = eng.timing_table()
+
+    # ---- final qerror on the first eval vectors of the training stream ----
+    ne = min(a.eval_vectors, nvec)
+    E.check(lib.somhip_batch_winner_keys(cb.h, ds.h, W * B, ne, C.c_void_p(keys.data_ptr())))
+    eng.sync()
+    if world > 1:
+        dist.all_reduce(keys[:ne], op=dist.ReduceOp.MIN)
+    hk = keys[:ne].cpu().numpy().view(np.uint64)
+    diffs = (hk >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    qerr = float(E.qerror_sum(diffs) / np.float32(ne))
+
+    out = None
+    if rank == 0:
+        value = K * B / elapsed
+        # dominant kernel of the timed region, by total time
+        kname, (kl, kms) = max(table.items(), key=lambda kv: kv[1][1])
+        n_local = r1 - r0
+        avg_s = (kms / max(kl, 1)) * 1e-3
+        if kname == "k_scan_exact":
+            # direct-form distance: sub, mul, add per (row, sample, dim); SURVEY.md 8(d): 3*N*d per vector
+            alg = 3.0 * n_local * d * B
+            roof = {"kernel": kname, "bound": "mfma", "achieved": alg / avg_s / 1e12, "peak": PEAK_F32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": alg / avg_s / 1e12 / PEAK_F32_TFLOPS, "traffic": None,
+                    "launches": kl, "avg_launch_ms": avg_s * 1e3,
+                    "note": "exact fp32 direct-form scan on the vector ALU (no FMA allowed: 1 flop/instr, "
+                            "ceiling = peak/2); priced against the fp32 matrix/vector peak"}
+        else:
+            # streaming kernels: every code row read once (+ written where it changed) per launch
+            alg = 4.0 * n_local * d
+            roof = {"kernel": kname, "bound": "hbm", "achieved": alg / avg_s / 1e9, "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": alg / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                    "launches": kl, "avg_launch_ms": avg_s * 1e3,
+                    "note": "algorithmic bytes = one read of the local codebook shard per launch"}
+        cpu = cpu_baseline(a, init, data, xdim, ydim, d, radius) if (world == 1 and a.cpu_vectors > 0) else None
+        out = {
+            "metric": "training_vectors_per_sec", "value": value, "unit": "vectors/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "final_qerror": qerr,
+            "config": {"workload": "vsom 256x256 hexa bubble SOM, dim=512 (BASELINE.json configs[3])"
+                       if (xdim, ydim, d) == (256, 256, 512) else "vsom %dx%d hexa bubble SOM, dim=%d" % (xdim, ydim, d),
+                       "dim": d, "codebook_rows": N, "batch": B, "vectors": K * B, "alpha": a.alpha,
+                       "radius": radius, "alpha_type": "linear",
+                       "schedule": "mini-batch (winners per batch, in-order updates)" if B > 1 else "online (reference-exact)",
+                       "parallelism": "codebook rows sharded /%d, all-reduce(MIN) of (dist,idx) keys" % world
+                       if world > 1 else "single GPU"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernels_ms": {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in table.items() if v[0]},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def cpu_baseline(a, init, data, xdim, ydim, d, radius):
+    """The reference's own som_training (oracle/_ref, built from /root/reference) -- or, if that
+    is absent, our CPU restatement -- timed on this host, 1 core, on the first --cpu-vectors
+    vectors of the same stream with the same (compressed) schedule.  A reported baseline only."""
+    try:
+        import oracle
+    except Exception as exc:                                  # pragma: no cover
+        return {"error": "oracle package not importable: %s" % exc}
+    n = a.cpu_vectors
+    x = data[:n].cpu().numpy()
+    t0 = time.perf_counter()
+    if oracle.ref_available():
+        ref = oracle.RefHarness()
+        ref.som_train(init, xdim, ydim, 3, 1, x, n, a.alpha, radius, trace=False)
+        secs, kind = ref.last_seconds, "reference"
+    else:
+        orc = oracle.Oracle()
+        t0 = time.perf_counter()
+        orc.som_train(init, xdim, ydim, 3, 1, x, n, a.alpha, radius, trace=False)
+        secs, kind = time.perf_counter() - t0, "port"
+    return {"value": n / secs, "unit": "vectors/s", "cores": 1, "kind": kind,
+            "host_cores": os.cpu_count(),
+            "sample": "som_training on the first %d vectors of the same stream, same map, radius %g->1 and "
+                      "alpha over those %d iterations; epoch loop only (%.1f s)" % (n, radius, n, secs)}
+
+
+if __name__ == "__main__":
+    main()

@@ -511,9 +511,93 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
 // twice, and written only where it changed.  The winner of iteration t is folded into
 // slot[t] with a 64-bit atomic min; the next launch (stream order) reads it.
 //   has_prev / has_cur select prologue (no update yet) and flush (no search left).
-// A wave streams its 64 rows U chunks (U KiB) at a time, all U loads issued before the
-// first use, so a CU with 4 such waves keeps 4*U KiB of HBM reads in flight.
+// A wave streams its 64 rows through two register buffers of U chunks (U KiB) each: the
+// next buffer's loads are issued before the current one is consumed, and the loop body
+// is branch-free (UPD / SEARCH / MASKED / VEC are compile-time) so the waits the
+// compiler places are counted, not drains.
 // =====================================================================================
+template <bool VEC>
+__device__ __forceinline__ float4 load_x4(const float *__restrict__ xr, int q, int d) {
+  if (VEC) return reinterpret_cast<const float4 *>(xr)[q];     // wave-uniform
+  float4 x;
+  x.x = q * 4 + 0 < d ? xr[q * 4 + 0] : 0.f;
+  x.y = q * 4 + 1 < d ? xr[q * 4 + 1] : 0.f;
+  x.z = q * 4 + 2 < d ? xr[q * 4 + 2] : 0.f;
+  x.w = q * 4 + 3 < d ? xr[q * 4 + 3] : 0.f;
+  return x;
+}
+
+template <bool UPD, bool SEARCH, bool MASKED, bool VEC>
+__device__ __forceinline__ void online_chunk(const CbView &cb, int64_t g, int lane, int q, float4 c,
+                                             bool upd, float a, const float *__restrict__ xp,
+                                             const float *__restrict__ xc,
+                                             const uint8_t *__restrict__ mp,
+                                             const uint8_t *__restrict__ mc, float &acc) {
+  if (UPD) {
+    const float4 x = load_x4<VEC>(xp, q, cb.d);
+    if (upd) {
+      const float4 n = adapt4(c, x, a);
+      if (MASKED) {
+        if (q * 4 + 0 < cb.d && mp[q * 4 + 0] == 0) c.x = n.x;
+        if (q * 4 + 1 < cb.d && mp[q * 4 + 1] == 0) c.y = n.y;
+        if (q * 4 + 2 < cb.d && mp[q * 4 + 2] == 0) c.z = n.z;
+        if (q * 4 + 3 < cb.d && mp[q * 4 + 3] == 0) c.w = n.w;
+      } else {
+        c = n;
+      }
+      *tile_ptr_w(cb, g, q, lane) = c;
+    }
+  }
+  if (SEARCH) {
+    const float4 x = load_x4<VEC>(xc, q, cb.d);
+    if (MASKED) {
+      if (q * 4 + 0 < cb.d && mc[q * 4 + 0] == 0) acc = sq_acc(acc, c.x, x.x);
+      if (q * 4 + 1 < cb.d && mc[q * 4 + 1] == 0) acc = sq_acc(acc, c.y, x.y);
+      if (q * 4 + 2 < cb.d && mc[q * 4 + 2] == 0) acc = sq_acc(acc, c.z, x.z);
+      if (q * 4 + 3 < cb.d && mc[q * 4 + 3] == 0) acc = sq_acc(acc, c.w, x.w);
+    } else {
+      acc = sq_acc(acc, c.x, x.x);
+      acc = sq_acc(acc, c.y, x.y);
+      acc = sq_acc(acc, c.z, x.z);
+      acc = sq_acc(acc, c.w, x.w);
+    }
+  }
+}
+
+template <bool UPD, bool SEARCH, bool MASKED, bool VEC, int U>
+__device__ __forceinline__ float online_stream(const CbView &cb, int64_t g, int lane, bool upd, float a,
+                                               const float *__restrict__ xp,
+                                               const float *__restrict__ xc,
+                                               const uint8_t *__restrict__ mp,
+                                               const uint8_t *__restrict__ mc) {
+  float acc = 0.0f;
+  float4 bufA[U], bufB[U];
+  const int nfull = (cb.d4 / (2 * U)) * (2 * U);
+  const int last = cb.d4 - 1;
+  if (nfull > 0) {
+#pragma unroll
+    for (int u = 0; u < U; u++) bufA[u] = *tile_ptr(cb, g, u, lane);
+    for (int qb = 0; qb < nfull; qb += 2 * U) {
+#pragma unroll
+      for (int u = 0; u < U; u++) bufB[u] = *tile_ptr(cb, g, qb + U + u, lane);
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        online_chunk<UPD, SEARCH, MASKED, VEC>(cb, g, lane, qb + u, bufA[u], upd, a, xp, xc, mp, mc, acc);
+#pragma unroll
+      for (int u = 0; u < U; u++) {            // prefetch for the next trip (clamped at the end)
+        int q = qb + 2 * U + u;
+        bufA[u] = *tile_ptr(cb, g, q < last ? q : last, lane);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        online_chunk<UPD, SEARCH, MASKED, VEC>(cb, g, lane, qb + U + u, bufB[u], upd, a, xp, xc, mp, mc, acc);
+    }
+  }
+  for (int q = nfull; q < cb.d4; q++)          // tail chunks
+    online_chunk<UPD, SEARCH, MASKED, VEC>(cb, g, lane, q, *tile_ptr(cb, g, q, lane), upd, a, xp, xc, mp, mc, acc);
+  return acc;
+}
+
 template <bool GAUSS, bool MASKED, int U>
 __global__ __launch_bounds__(256) void k_som_online_step(CbView cb, const float *__restrict__ rows,
                                                          const uint8_t *__restrict__ mask,
@@ -561,66 +645,14 @@ __global__ __launch_bounds__(256) void k_som_online_step(CbView cb, const float 
   const uint8_t *mp = MASKED ? mask + prev_row * cb.d : nullptr;
   const uint8_t *mc = MASKED ? mask + cur_row * cb.d : nullptr;
   const bool vec = (cb.d & 3) == 0;
-  float acc = 0.0f;
-
-  for (int qb = 0; qb < cb.d4; qb += U) {
-    float4 cc[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      int q = qb + u < cb.d4 ? qb + u : cb.d4 - 1;
-      cc[u] = *tile_ptr(cb, g, q, lane);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int q = qb + u;
-      if (q < cb.d4) {
-        float4 c = cc[u];
-        if (any_upd) {
-          float4 x;
-          if (vec) x = reinterpret_cast<const float4 *>(xp)[q];
-          else {
-            x.x = q * 4 + 0 < cb.d ? xp[q * 4 + 0] : 0.f;
-            x.y = q * 4 + 1 < cb.d ? xp[q * 4 + 1] : 0.f;
-            x.z = q * 4 + 2 < cb.d ? xp[q * 4 + 2] : 0.f;
-            x.w = q * 4 + 3 < cb.d ? xp[q * 4 + 3] : 0.f;
-          }
-          if (upd) {
-            float4 n = adapt4(c, x, a);
-            if (MASKED) {
-              if (q * 4 + 0 < cb.d && mp[q * 4 + 0] == 0) c.x = n.x;
-              if (q * 4 + 1 < cb.d && mp[q * 4 + 1] == 0) c.y = n.y;
-              if (q * 4 + 2 < cb.d && mp[q * 4 + 2] == 0) c.z = n.z;
-              if (q * 4 + 3 < cb.d && mp[q * 4 + 3] == 0) c.w = n.w;
-            } else {
-              c = n;
-            }
-            *tile_ptr_w(cb, g, q, lane) = c;
-          }
-        }
-        if (search) {
-          float4 x;
-          if (vec) x = reinterpret_cast<const float4 *>(xc)[q];
-          else {
-            x.x = q * 4 + 0 < cb.d ? xc[q * 4 + 0] : 0.f;
-            x.y = q * 4 + 1 < cb.d ? xc[q * 4 + 1] : 0.f;
-            x.z = q * 4 + 2 < cb.d ? xc[q * 4 + 2] : 0.f;
-            x.w = q * 4 + 3 < cb.d ? xc[q * 4 + 3] : 0.f;
-          }
-          if (MASKED) {
-            if (q * 4 + 0 < cb.d && mc[q * 4 + 0] == 0) acc = sq_acc(acc, c.x, x.x);
-            if (q * 4 + 1 < cb.d && mc[q * 4 + 1] == 0) acc = sq_acc(acc, c.y, x.y);
-            if (q * 4 + 2 < cb.d && mc[q * 4 + 2] == 0) acc = sq_acc(acc, c.z, x.z);
-            if (q * 4 + 3 < cb.d && mc[q * 4 + 3] == 0) acc = sq_acc(acc, c.w, x.w);
-          } else {
-            acc = sq_acc(acc, c.x, x.x);
-            acc = sq_acc(acc, c.y, x.y);
-            acc = sq_acc(acc, c.z, x.z);
-            acc = sq_acc(acc, c.w, x.w);
-          }
-        }
-      }
-    }
-  }
+  float acc;
+#define ONLINE_GO(UU, SS)                                                                               \
+  acc = vec ? online_stream<UU, SS, MASKED, true, U>(cb, g, lane, upd, a, xp, xc, mp, mc)               \
+            : online_stream<UU, SS, MASKED, false, U>(cb, g, lane, upd, a, xp, xc, mp, mc)
+  if (any_upd && search) { ONLINE_GO(true, true); }
+  else if (search) { ONLINE_GO(false, true); }
+  else { ONLINE_GO(true, false); }
+#undef ONLINE_GO
   if (search) {
     uint64_t k = live ? make_key(acc, grow) : KEY_NONE;
     k = wave_min_u64(k);

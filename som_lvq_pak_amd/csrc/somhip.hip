@@ -523,7 +523,7 @@ static int som_scalars(const somhip_codebook *cb, const somhip_dataset *ds, cons
   return 0;
 }
 
-constexpr int ONLINE_U = 16;   // KiB of code rows a wave keeps in flight
+constexpr int ONLINE_U = 8;    // chunks (KiB) per register buffer; two buffers per wave
 template <bool G, bool M>
 static void launch_online(somhip_engine *e, const somhip_codebook *cb, const somhip_dataset *ds,
                           int64_t prev_row, int64_t cur_row, int has_prev, int has_cur,

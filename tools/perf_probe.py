@@ -38,6 +38,14 @@ def main():
         for k, (cnt, ms) in tab.items():
             if cnt:
                 print("     %-20s launches %6d  avg %9.3f us  total %9.3f ms" % (k, cnt, 1e3 * ms / cnt, ms))
+    eng.timing(False)
+    for label, kw, iters in (("online r=big (no events)", dict(radius=xdim / 2.0, batch=1), 1024),
+                             ("online r=3 (no events)", dict(radius=3.0, batch=1), 1024)):
+        t0 = time.time()
+        E.som_train(cb, ds, iters, 0.05, trace=False, **kw)
+        eng.sync()
+        dt = time.time() - t0
+        print("%-26s %8.1f vec/s  %.2f us/iter" % (label, iters / dt, 1e6 * dt / iters))
     cbytes = n * dim * 4
     print("codebook bytes %.1f MiB, scan flops/sample (3*N*d) %.1f M" % (cbytes / 2**20, 3 * n * dim / 1e6))
 
