@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--cpu-vectors", type=int, default=400,
                     help="vectors the CPU reference trains on for cpu_baseline (0 = skip)")
     ap.add_argument("--eval-vectors", type=int, default=8192)
+    ap.add_argument("--online-vectors", type=int, default=-1,
+                    help="also run the reference-exact online engine (batch 1) over the same schedule; "
+                         "-1 = the whole K*batch run when it is <= 600k vectors, 0 = skip")
     return ap.parse_args()
 
 
@@ -97,27 +100,25 @@ def main():
 
     eng = E.Engine(local)
     ds = E.Dataset(eng, device_ptr=data.data_ptr(), n=nvec, dim=d)
-    rows_per = (N + world - 1) // world
-    r0, r1 = rank * rows_per, min(N, (rank + 1) * rows_per)
+    from som_lvq_pak_amd.sharded import shard_rows
+    r0, r1 = shard_rows(N, world, rank)
     cb = E.Codebook(eng, init[r0:r1], E.TOPOL_HEXA, E.NEIGH_BUBBLE, xdim, ydim, row_offset=r0, n_global=N)
     lib = eng.lib
-    keys = torch.empty(max(B, a.eval_vectors), dtype=torch.int64, device=dev)
+
+    from som_lvq_pak_amd import sharded
+    cur_len = [length]
+    gshard = sharded.GpuShard(eng, cb, ds, lambda: SomParams(cur_len[0], a.alpha, radius, E.ALPHA_LINEAR,
+                                                             0, 0, max(B, 1), 0, 0, 0), max(B, a.eval_vectors))
+    ssom = sharded.ShardedSom(gshard, max(B, 1), nvec)
 
     def step(it0, data_first, count, length_):
-        p = SomParams(length_, a.alpha, radius, E.ALPHA_LINEAR, 0, 0, max(B, 1), it0, count, data_first)
         if world == 1:
+            p = SomParams(length_, a.alpha, radius, E.ALPHA_LINEAR, 0, 0, max(B, 1), it0, count, data_first)
             E.check(lib.somhip_som_train(cb.h, ds.h, C.byref(p), None, None))
             return
-        # two-phase: local shard winners -> all-reduce(MIN) of packed keys -> local update
-        E.check(lib.somhip_batch_winner_keys(cb.h, ds.h, data_first, count, C.c_void_p(keys.data_ptr())))
-        eng.sync()
-        kk = keys[:count]
-        # distance bits >= 0, so int64 order == uint64 order -- except the all-ones "no winner" key
-        kk.copy_(torch.where(kk < 0, torch.full_like(kk, 0x7FFFFFFFFFFFFFFF), kk))
-        dist.all_reduce(kk, op=dist.ReduceOp.MIN)
-        torch.cuda.current_stream().synchronize()
-        E.check(lib.somhip_som_batch_update(cb.h, ds.h, C.byref(p), it0, count, data_first,
-                                            C.c_void_p(keys.data_ptr())))
+        # local shard winners -> all-reduce(MIN) of packed keys (RCCL) -> local update
+        cur_len[0] = length_
+        ssom.step(it0, data_first, count)
 
     def barrier():
         eng.sync()
@@ -151,13 +152,32 @@ def main():
 
     # ---- final qerror on the first eval vectors of the training stream ----
     ne = min(a.eval_vectors, nvec)
-    E.check(lib.somhip_batch_winner_keys(cb.h, ds.h, W * B, ne, C.c_void_p(keys.data_ptr())))
+    ek = gshard.winner_keys(W * B, ne)
     eng.sync()
-    if world > 1:
-        dist.all_reduce(keys[:ne], op=dist.ReduceOp.MIN)
-    hk = keys[:ne].cpu().numpy().view(np.uint64)
-    diffs = (hk >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    sharded.allreduce_min_keys(ek)
+    diffs, _ = sharded.unpack_keys(ek.cpu().numpy())
     qerr = float(E.qerror_sum(diffs) / np.float32(ne))
+
+    # ---- the reference-exact online engine on the same stream and schedule (N = 1 only) ----
+    online = None
+    nonl = a.online_vectors if a.online_vectors >= 0 else (length if length <= 600000 else 0)
+    if world == 1 and B > 1 and nonl > 0:
+        nonl = min(nonl, length)
+        cb.upload(init[r0:r1])
+        eng.sync()
+        p = SomParams(length, a.alpha, radius, E.ALPHA_LINEAR, 0, 0, 1, 0, nonl, W * B)
+        t2 = time.perf_counter()
+        E.check(lib.somhip_som_train(cb.h, ds.h, C.byref(p), None, None))
+        eng.sync()
+        t3 = time.perf_counter()
+        ek = gshard.winner_keys(W * B, ne)
+        eng.sync()
+        d2, _ = sharded.unpack_keys(ek.cpu().numpy())
+        q2 = float(E.qerror_sum(d2) / np.float32(ne))
+        online = {"schedule": "online, batch 1: the reference's algorithm, bit-exact with the CPU reference",
+                  "vectors": nonl, "value": nonl / (t3 - t2), "unit": "vectors/s",
+                  "final_qerror": q2 if nonl == length else None,
+                  "minibatch_qerror_rel_delta": (qerr - q2) / q2 if nonl == length else None}
 
     out = None
     if rank == 0:
@@ -197,6 +217,7 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "online_exact": online,
             "kernels_ms": {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in table.items() if v[0]},
         }
         print(json.dumps(out))

@@ -1,0 +1,121 @@
+"""Row-sharded SOM training step across ranks (one process per GPU, torch.distributed).
+
+The codebook is split into contiguous row blocks; every rank sees the same batch.  Per batch:
+  1. each rank finds the best row of ITS shard for every sample   -> packed keys [B]
+  2. one all-reduce(MIN) of the keys                              -> global winners
+  3. each rank applies the batch's neighbourhood updates to its own rows, in iteration order
+The update of a row needs only the sample, the winner's lattice coordinates and the
+per-iteration scalars, never another row, so there is no halo and no other collective.
+
+Keys are uint64 = (fp32 bits of the squared distance << 32) | global row index.  Distances
+are >= 0, so unsigned order == (distance, index) order and MIN reproduces find_winner_euc
+over the whole codebook, lowest index winning ties (reference lvq_pak.c:79).  torch has no
+uint64 reductions; int64 order agrees with uint64 order for every key whose top bit is clear,
+i.e. every real key -- only the all-ones "no winner" key must be mapped first.
+
+The local work is behind a small interface so the same orchestration runs on GPUs (bench.py:
+`GpuShard`, RCCL) and in the CPU tests (gloo, a checker-backed shard).
+"""
+import numpy as np
+
+KEY_NONE_I64 = -1                       # 0xFFFF_FFFF_FFFF_FFFF seen as int64
+KEY_MAX_I64 = 0x7FFFFFFFFFFFFFFF
+
+
+def shard_rows(n_global, world, rank):
+    """Contiguous block [r0, r1) of rank `rank`; blocks differ by at most one row group."""
+    per = (n_global + world - 1) // world
+    r0 = min(n_global, rank * per)
+    return r0, min(n_global, r0 + per)
+
+
+def pack_keys(diff, index):
+    """numpy: (float32 squared distance >= 0, row index) -> uint64 keys."""
+    bits = np.ascontiguousarray(diff, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return (bits << np.uint64(32)) | np.asarray(index, dtype=np.uint64)
+
+
+def unpack_keys(keys):
+    keys = np.asarray(keys).view(np.uint64)
+    diff = (keys >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    index = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    return diff, index
+
+
+def allreduce_min_keys(keys, group=None):
+    """In-place global MIN of packed keys held in an int64 torch tensor (any device)."""
+    import torch
+    import torch.distributed as dist
+    keys.copy_(torch.where(keys < 0, torch.full_like(keys, KEY_MAX_I64), keys))
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
+    return keys
+
+
+class ShardedSom:
+    """Mini-batch SOM training over a row-sharded codebook.
+
+    `shard` provides:
+        winner_keys(first, count) -> int64 torch tensor [count] of this shard's packed keys
+        update(it0, count, first, keys)  apply iterations [it0, it0+count) to the local rows
+        sync()                           make the shard's device work visible to torch
+    """
+
+    def __init__(self, shard, batch, n_data):
+        self.shard = shard
+        self.batch = batch
+        self.n_data = n_data
+
+    def step(self, it0, data_first, count):
+        keys = self.shard.winner_keys(data_first, count)
+        self.shard.sync()
+        allreduce_min_keys(keys)
+        self.shard.sync_torch()
+        self.shard.update(it0, count, data_first, keys)
+        return keys
+
+    def train(self, length, start_iter=0, count=None, data_first=None):
+        count = length - start_iter if count is None else count
+        data_first = start_iter % self.n_data if data_first is None else data_first
+        off = 0
+        winners = []
+        while off < count:
+            it0 = start_iter + off
+            c = min(self.batch - (it0 % self.batch), count - off)
+            keys = self.step(it0, (data_first + off) % self.n_data, c)
+            winners.append(keys.clone())
+            off += c
+        return winners
+
+
+class GpuShard:
+    """The local half on an MI355X, through the C ABI (somhip_batch_winner_keys /
+    somhip_som_batch_update).  `keys` is a torch int64 tensor on the same device whose
+    storage the engine writes directly."""
+
+    def __init__(self, engine, codebook, dataset, params_factory, max_batch):
+        import torch
+        self.e, self.cb, self.ds = engine, codebook, dataset
+        self.params_factory = params_factory
+        self.keys = torch.empty(max_batch, dtype=torch.int64, device=torch.device("cuda", engine.device))
+
+    def winner_keys(self, first, count):
+        import ctypes as C
+        from ._lib import check
+        check(self.e.lib.somhip_batch_winner_keys(self.cb.h, self.ds.h, first, count,
+                                                  C.c_void_p(self.keys.data_ptr())))
+        return self.keys[:count]
+
+    def update(self, it0, count, first, keys):
+        import ctypes as C
+        from ._lib import check
+        p = self.params_factory()
+        check(self.e.lib.somhip_som_batch_update(self.cb.h, self.ds.h, C.byref(p), it0, count, first,
+                                                 C.c_void_p(keys.data_ptr())))
+
+    def sync(self):
+        self.e.sync()
+
+    def sync_torch(self):
+        import torch
+        torch.cuda.current_stream().synchronize()
