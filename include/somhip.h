@@ -49,6 +49,18 @@ void somhip_engine_destroy(somhip_engine *e);
 void *somhip_engine_stream(somhip_engine *e);
 int  somhip_engine_sync(somhip_engine *e);
 
+/* Winner-search implementation for runs of samples (mini-batch training, find_winners k=1):
+ *   SOMHIP_SCAN_DIRECT  direct-form fp32 scan on the vector ALU (the reference's arithmetic)
+ *   SOMHIP_SCAN_MFMA    fp32-MFMA distance GEMM as a pre-filter with a rigorous error bound +
+ *                       exact re-rank of the surviving rows by the direct-form arithmetic
+ * Both return bit-identical winners; MFMA is the default where it applies (no masks). */
+enum { SOMHIP_SCAN_DIRECT = 0, SOMHIP_SCAN_MFMA = 1 };
+int  somhip_engine_set_scan_mode(somhip_engine *e, int mode);
+/* cumulative re-rank statistics of the MFMA path since engine creation:
+ * out[0] = row groups re-ranked, out[1] = rows re-ranked, out[2] = max groups for one sample,
+ * out[3] = samples searched */
+int  somhip_scan_stats(somhip_engine *e, uint64_t out[4]);
+
 /* ---- codebook mirror -------------------------------------------------------
  * rows: host, row-major [n_rows][dim] fp32, row k = list position k of the
  * reference's codebook (datafile.c:781,836) = map unit (k % xdim, k / xdim)

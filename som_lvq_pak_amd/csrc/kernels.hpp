@@ -308,6 +308,279 @@ __global__ void k_merge_topk(const uint64_t *__restrict__ partial, int nblk, int
 }
 
 // =====================================================================================
+// K2: the throughput path of the winner search -- an fp32-MFMA distance GEMM used as a
+// PRE-FILTER, followed by an exact re-rank (K2r) of the few rows it cannot rule out.
+//
+//   s~[n,b] = ||c_n||^2 - 2 <c_n, x_b>          (MFMA v_mfma_f32_32x32x2_f32, fp32 fma chain)
+//
+// differs from the reference's direct-form value d[n,b] = sum_i fl(fl(c_i-x_i)^2) by
+// rounding only; with u = 2^-24, g_k = k*u/(1-k*u):
+//   |s~ + ||x||^2 - d|  <=  2 g_{d+2} (||x|| + ||c||)^2          
+// so every row that can be the exact winner (or tie with it) satisfies
+//   s~[n,b] <= min_n s~[n,b] + tau_b,   tau_b = 4 g_{d+2} (||x_b|| + max_n ||c_n||)^2 .
+// Per (row group of 64 codes, sample) the kernel keeps the group minimum and a 64-bit
+// mask of rows within tau_b of it; K2r recomputes the masked rows of the groups within
+// tau_b of the global minimum with the reference's own arithmetic and takes the exact
+// (distance, index) minimum.  Result: bit-identical to k_scan_exact / find_winner_euc.
+//
+// Workgroup = 4 waves as 2 (row groups) x 2 (pairs of 32-sample tiles): a 128 x 128 tile
+// of the distance matrix, K = d in stages of QB chunks (4*QB dims) through LDS, two
+// stages (register-staged prefetch of the next while the current feeds the MFMAs).
+// Codes are the A operand (rows -> accumulator registers), samples the B operand
+// (column -> lane), so a sample's minimum over codes is an in-register reduction.
+// =====================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MF_QB = 8;                  // chunks per stage: 32 dims
+
+__global__ void k_row_norms(CbView cb, float *__restrict__ cn, unsigned int *__restrict__ cn_max_bits) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  if (g >= cb.ngroups) return;
+  float acc = 0.0f;
+  for (int q = 0; q < cb.d4; q++) {
+    const float4 c = *tile_ptr(cb, g, q, lane);
+    acc += c.x * c.x; acc += c.y * c.y; acc += c.z * c.z; acc += c.w * c.w;
+  }
+  const int64_t row = g * WAVE + lane;
+  cn[row] = row < cb.n ? acc : 3.0e38f;            // padding rows can never be candidates
+  float m = row < cb.n ? acc : 0.0f;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, WAVE));
+  if (lane == 0) atomicMax(cn_max_bits, __float_as_uint(m));   // values >= 0: bit order = value order
+}
+
+// tau[b] for the samples of a run (one wave per sample)
+__global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int d, int64_t first,
+                             int64_t count, const unsigned int *__restrict__ cn_max_bits,
+                             float *__restrict__ tau) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= count) return;
+  const float *x = rows + ((first + b) % n_rows) * d;
+  double acc = 0.0;
+  for (int i = lane; i < d; i += WAVE) { double v = x[i]; acc += v * v; }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, WAVE);
+  if (lane == 0) {
+    const double u = 5.9604644775390625e-08;                         // 2^-24
+    const double k = (d + 2) * u;
+    const double gam = k / (1.0 - k);
+    const double cmax = sqrt(static_cast<double>(__uint_as_float(*cn_max_bits)) * (1.0 + 4.0 * d * u));
+    const double s = sqrt(acc) + cmax;
+    const double t = 4.0 * gam * s * s * 1.001;
+    float tf = static_cast<float>(t);
+    if (static_cast<double>(tf) < t) tf = __uint_as_float(__float_as_uint(tf) + 1);   // round up
+    tau[b] = tf;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_dist_mfma(CbView cb, const float4 *__restrict__ xt,
+                                                      const float *__restrict__ cn,
+                                                      const float *__restrict__ tau, int64_t count,
+                                                      int64_t bpad, float *__restrict__ wmin,
+                                                      uint64_t *__restrict__ wmask) {
+  // [stage][ 2 groups x QB x 64 | 4 tiles x QB x 32 ] float4
+  __shared__ float4 lds[2][2 * MF_QB * 64 + 4 * MF_QB * 32];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int64_t g0 = static_cast<int64_t>(blockIdx.y) * 2;          // first row group of the WG
+  const int64_t st0 = static_cast<int64_t>(blockIdx.x) * 4;         // first sample tile of the WG
+  const int64_t nst = bpad / 32;
+
+  // ---- staging map: 32 pieces of 1 KiB per stage, 8 per wave, one float4 per lane each.
+  // piece p < 16: codes, group p/8, chunk p%8; p >= 16: samples, tile (p-16)/4, chunk pair (p-16)%4
+  const float4 *src[8];
+  int dst[8];
+  int stride[8];                     // float4 stride between stages in global memory
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int p = wave * 8 + i;
+    if (p < 16) {
+      const int gi = p >> 3, q = p & 7;
+      int64_t g = g0 + gi < cb.ngroups ? g0 + gi : cb.ngroups - 1;
+      src[i] = reinterpret_cast<const float4 *>(cb.tiles) + (g * cb.d4 + q) * 64 + lane;
+      dst[i] = (gi * MF_QB + q) * 64 + lane;
+      stride[i] = MF_QB * 64;
+    } else {
+      const int ti = (p - 16) >> 2, qp = (p - 16) & 3;
+      int64_t st = st0 + ti < nst ? st0 + ti : nst - 1;
+      src[i] = xt + (st * cb.d4 + qp * 2) * 32 + lane;              // chunks 2qp, 2qp+1
+      dst[i] = 2 * MF_QB * 64 + (ti * MF_QB + qp * 2) * 32 + lane;
+      stride[i] = MF_QB * 32;
+    }
+  }
+  const int nstage = (cb.d4 + MF_QB - 1) / MF_QB;
+  // chunks beyond d4 (d4 not a multiple of QB) must contribute zeros
+  auto stage_load = [&](float4 (&r)[8], int s) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int p = wave * 8 + i;
+      int q = s * MF_QB + (p < 16 ? (p & 7) : ((p - 16) & 3) * 2 + (lane >> 5));
+      r[i] = q < cb.d4 ? src[i][static_cast<int64_t>(s) * stride[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+  float4 regs[8];
+  stage_load(regs, 0);
+#pragma unroll
+  for (int i = 0; i < 8; i++) lds[0][dst[i]] = regs[i];
+  __syncthreads();
+
+  for (int s = 0; s < nstage; s++) {
+    const int cur = s & 1;
+    if (s + 1 < nstage) stage_load(regs, s + 1);
+    const float4 *lc = &lds[cur][(wr * MF_QB) * 64];
+    const float4 *lx = &lds[cur][2 * MF_QB * 64 + (wc * 2 * MF_QB) * 32];
+#pragma unroll
+    for (int q = 0; q < MF_QB; q++) {
+      const float4 a0 = lc[q * 64 + l31];
+      const float4 a1 = lc[q * 64 + 32 + l31];
+      const float4 b0 = lx[q * 32 + l31];
+      const float4 b1 = lx[(MF_QB + q) * 32 + l31];
+      // MFMA 32x32x2: lanes 0-31 carry k, lanes 32-63 carry k+1 (same rule for A and B)
+      const float a0k = half ? a0.y : a0.x, a0m = half ? a0.w : a0.z;
+      const float a1k = half ? a1.y : a1.x, a1m = half ? a1.w : a1.z;
+      const float b0k = half ? b0.y : b0.x, b0m = half ? b0.w : b0.z;
+      const float b1k = half ? b1.y : b1.x, b1m = half ? b1.w : b1.z;
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0k, b0k, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0k, b1k, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1k, b0k, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1k, b1k, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0m, b0m, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0m, b1m, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1m, b0m, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1m, b1m, acc[1][1], 0, 0, 0);
+    }
+    if (s + 1 < nstage) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) lds[cur ^ 1][dst[i]] = regs[i];
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: s~ = cn - 2 dot, group minimum per sample, candidate mask
+  const int64_t g = g0 + wr;
+  if (g >= cb.ngroups) return;
+  // accumulator register r of block i is code row 32 i + (r&3) + 8 (r>>2) + 4 half
+  float4 cnv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      cnv[i][k] = *reinterpret_cast<const float4 *>(cn + g * 64 + 32 * i + 8 * k + 4 * half);
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int64_t st = st0 + wc * 2 + j;
+    if (st >= nst) continue;
+    const int64_t b = st * 32 + l31;
+    float sv[2][16];
+    float m = 3.4e38f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float4 c4 = cnv[i][r >> 2];
+        const float cnr = (r & 3) == 0 ? c4.x : (r & 3) == 1 ? c4.y : (r & 3) == 2 ? c4.z : c4.w;
+        const float v = cnr - 2.0f * acc[i][j][r];
+        sv[i][r] = v;
+        m = fminf(m, v);
+      }
+    m = fminf(m, __shfl_xor(m, 32, WAVE));
+    const float thr = m + (b < count ? tau[b] : 0.0f);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (sv[i][r] <= thr) bits |= 1u << (16 * i + r);
+    const uint32_t other = __shfl_xor(bits, 32, WAVE);
+    if (half == 0 && b < bpad) {
+      wmin[g * bpad + b] = m;
+      wmask[g * bpad + b] = static_cast<uint64_t>(bits) | (static_cast<uint64_t>(other) << 32);
+    }
+  }
+}
+
+// =====================================================================================
+// K2r: exact re-rank.  One wave per sample: global minimum of the group minima, then
+// for every group within tau of it, the masked rows' distances with the reference's
+// arithmetic (lane = row, dims in order, sub/mul/add), exact (distance, index) minimum.
+// stats[0] += groups re-ranked, stats[1] += rows re-ranked, stats[2] = max groups/sample.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_rerank(CbView cb, const float *__restrict__ rows,
+                                                int64_t n_rows, int64_t first, int64_t count,
+                                                int64_t bpad, const float *__restrict__ wmin,
+                                                const uint64_t *__restrict__ wmask,
+                                                const float *__restrict__ tau,
+                                                uint64_t *__restrict__ keys,
+                                                unsigned long long *__restrict__ stats) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= count) return;
+  float m = 3.4e38f;
+  for (int64_t g = lane; g < cb.ngroups; g += WAVE) m = fminf(m, wmin[g * bpad + b]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off, WAVE));
+  const float thr = m + tau[b];
+  const float *x = rows + ((first + b) % n_rows) * cb.d;
+  const bool vec = (cb.d & 3) == 0;
+  uint64_t best = KEY_NONE;
+  unsigned ngroups_done = 0, nrows_done = 0;
+  for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
+    const int64_t gl = gb + lane;
+    const bool q = gl < cb.ngroups && wmin[gl * bpad + b] <= thr;
+    uint64_t ball = __ballot(q);
+    while (ball) {
+      const int t = __builtin_ctzll(ball);
+      ball &= ball - 1;
+      const int64_t g = gb + t;
+      const uint64_t mask = wmask[g * bpad + b];
+      // lane -> code row of the group: the mask bit of row rr is
+      //   half = (rr>>2)&1, i = rr>>5, r = (rr&3) + 4*((rr&31)>>3)  -> bit 32*half + 16*i + r
+      const int rr = lane;
+      const int hbit = (rr >> 2) & 1, ib = rr >> 5, rb = (rr & 3) + 4 * ((rr & 31) >> 3);
+      const bool mine = (mask >> (32 * hbit + 16 * ib + rb)) & 1ull;
+      const int64_t row = g * WAVE + lane;
+      float acc = 0.0f;
+      for (int qq = 0; qq < cb.d4; qq++) {
+        const float4 c = *tile_ptr(cb, g, qq, lane);
+        const float4 xv = vec ? reinterpret_cast<const float4 *>(x)[qq]
+                              : make_float4(qq * 4 + 0 < cb.d ? x[qq * 4 + 0] : 0.f,
+                                            qq * 4 + 1 < cb.d ? x[qq * 4 + 1] : 0.f,
+                                            qq * 4 + 2 < cb.d ? x[qq * 4 + 2] : 0.f,
+                                            qq * 4 + 3 < cb.d ? x[qq * 4 + 3] : 0.f);
+        acc = sq_acc(acc, c.x, xv.x);
+        acc = sq_acc(acc, c.y, xv.y);
+        acc = sq_acc(acc, c.z, xv.z);
+        acc = sq_acc(acc, c.w, xv.w);
+      }
+      const bool ok = mine && row < cb.n;
+      const uint64_t k = ok ? make_key(acc, static_cast<uint32_t>(row + cb.row_offset)) : KEY_NONE;
+      best = k < best ? k : best;
+      ngroups_done++;
+      nrows_done += __popcll(mask);
+    }
+  }
+  best = wave_min_u64(best);
+  if (lane == 0) {
+    keys[b] = best;
+    atomicAdd(stats + 0, static_cast<unsigned long long>(ngroups_done));
+    atomicAdd(stats + 1, static_cast<unsigned long long>(nrows_done));
+    atomicMax(stats + 2, static_cast<unsigned long long>(ngroups_done));
+  }
+}
+
+// =====================================================================================
 // K1m: masked variant, one sample per launch column (rare path: data with 'x'
 // components, lvq_pak.c:65-69).  mask is wave-uniform per component.
 // =====================================================================================

@@ -57,11 +57,15 @@ enum KernelId {
   KID_SCAN_MASKED,
   KID_LAYOUT,
   KID_DECODE,
+  KID_DIST_MFMA,
+  KID_RERANK,
+  KID_NORMS,
   KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {
     "k_scan_exact", "k_som_update_run", "k_som_online_step", "k_lvq_online_step",
-    "k_pack_samples", "k_merge_topk", "k_scan_masked", "k_layout", "k_decode_winners"};
+    "k_pack_samples", "k_merge_topk", "k_scan_masked", "k_layout", "k_decode_winners",
+    "k_dist_mfma", "k_rerank", "k_norms_tau"};
 extern "C" int somhip_kernel_count(void) { return KID_COUNT; }
 extern "C" const char *somhip_kernel_name(int i) { return (i >= 0 && i < KID_COUNT) ? kKernelNames[i] : ""; }
 
@@ -69,14 +73,17 @@ struct somhip_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   bool timing = false;
+  int scan_mode = SOMHIP_SCAN_MFMA;
+  unsigned long long *d_stats = nullptr;     // [4] re-rank statistics (device)
+  uint64_t samples_searched = 0;
   struct Pending { int kid; hipEvent_t a, b; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> pool;
   int64_t launches[KID_COUNT] = {0};
   double total_ms[KID_COUNT] = {0};
   // reusable device scratch
-  void *scratch[8] = {nullptr};
-  size_t scratch_bytes[8] = {0};
+  void *scratch[12] = {nullptr};
+  size_t scratch_bytes[12] = {0};
 };
 
 static int engine_scratch(somhip_engine *e, int slot, size_t bytes, void **out) {
@@ -143,6 +150,8 @@ extern "C" int somhip_engine_create(int device, somhip_engine **out) {
   somhip_engine *e = new somhip_engine();
   e->device = device;
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc((void **)&e->d_stats, 4 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(e->d_stats, 0, 4 * sizeof(unsigned long long)));
   *out = e;
   return 0;
 }
@@ -152,7 +161,8 @@ extern "C" void somhip_engine_destroy(somhip_engine *e) {
   (void)hipStreamSynchronize(e->stream);
   for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->pool) (void)hipEventDestroy(ev);
-  for (int i = 0; i < 8; i++) if (e->scratch[i]) (void)hipFree(e->scratch[i]);
+  for (int i = 0; i < 12; i++) if (e->scratch[i]) (void)hipFree(e->scratch[i]);
+  if (e->d_stats) (void)hipFree(e->d_stats);
   (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -160,6 +170,18 @@ extern "C" void *somhip_engine_stream(somhip_engine *e) { return e ? (void *)e->
 extern "C" int somhip_engine_sync(somhip_engine *e) {
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+extern "C" int somhip_engine_set_scan_mode(somhip_engine *e, int mode) {
+  if (mode != SOMHIP_SCAN_DIRECT && mode != SOMHIP_SCAN_MFMA) return fail("somhip_engine_set_scan_mode: bad mode %d", mode);
+  e->scan_mode = mode;
+  return 0;
+}
+extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[4]) {
+  unsigned long long h[4];
+  HIPCHK(hipMemcpyAsync(h, e->d_stats, sizeof h, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = e->samples_searched;
   return 0;
 }
 extern "C" int somhip_timing_enable(somhip_engine *e, int on) { CHK(timing_flush(e)); e->timing = on != 0; return 0; }
@@ -206,6 +228,8 @@ struct somhip_codebook {
   int64_t n_global = 0;
   int32_t *d_labels = nullptr;     // [n] local rows
   float *d_talpha = nullptr;       // [n] OLVQ1 rates
+  float *d_cn = nullptr;           // [ngroups*64] squared row norms (MFMA pre-filter)
+  unsigned int *d_cnmax = nullptr; // bits of max squared norm
 };
 struct somhip_dataset {
   somhip_engine *e = nullptr;
@@ -298,6 +322,8 @@ extern "C" void somhip_codebook_destroy(somhip_codebook *cb) {
   if (cb->v.tiles) (void)hipFree(cb->v.tiles);
   if (cb->d_labels) (void)hipFree(cb->d_labels);
   if (cb->d_talpha) (void)hipFree(cb->d_talpha);
+  if (cb->d_cn) (void)hipFree(cb->d_cn);
+  if (cb->d_cnmax) (void)hipFree(cb->d_cnmax);
   delete cb;
 }
 
@@ -368,6 +394,47 @@ static int check_pair(const somhip_codebook *cb, const somhip_dataset *ds, const
   return 0;
 }
 
+constexpr int64_t MFMA_MIN_SAMPLES = 32;
+
+// MFMA pre-filter + exact re-rank (kernels.hpp K2/K2r); xt = packed sample tiles of the run
+static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
+                          const float4 *xt, int64_t nsb, uint64_t *d_keys) {
+  somhip_engine *e = cb->e;
+  const int64_t bpad = nsb * SCAN_S;
+  if (!cb->d_cn) {
+    HIPCHK(hipMalloc((void **)&cb->d_cn, sizeof(float) * (size_t)cb->v.ngroups * WAVE));
+    HIPCHK(hipMalloc((void **)&cb->d_cnmax, sizeof(unsigned int)));
+  }
+  void *dtau, *dwmin, *dwmask;
+  CHK(engine_scratch(e, 5, sizeof(float) * (size_t)bpad, &dtau));
+  CHK(engine_scratch(e, 6, sizeof(float) * (size_t)cb->v.ngroups * bpad, &dwmin));
+  CHK(engine_scratch(e, 7, sizeof(uint64_t) * (size_t)cb->v.ngroups * bpad, &dwmask));
+  HIPCHK(hipMemsetAsync(cb->d_cnmax, 0, sizeof(unsigned int), e->stream));
+  {
+    LaunchTimer t(e, KID_NORMS);
+    hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((cb->v.ngroups + 3) / 4)), dim3(256), 0, e->stream,
+                       cb->v, cb->d_cn, cb->d_cnmax);
+    hipLaunchKernelGGL(k_sample_tau, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, e->stream,
+                       ds->d_rows, ds->n, ds->d, first, count, (const unsigned int *)cb->d_cnmax, (float *)dtau);
+  }
+  HIPCHK(hipGetLastError());
+  {
+    LaunchTimer t(e, KID_DIST_MFMA);
+    dim3 grid((unsigned)((nsb + 3) / 4), (unsigned)((cb->v.ngroups + 1) / 2));
+    hipLaunchKernelGGL(k_dist_mfma, grid, dim3(256), 0, e->stream, cb->v, xt, (const float *)cb->d_cn,
+                       (const float *)dtau, count, bpad, (float *)dwmin, (uint64_t *)dwmask);
+  }
+  HIPCHK(hipGetLastError());
+  {
+    LaunchTimer t(e, KID_RERANK);
+    hipLaunchKernelGGL(k_rerank, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, e->stream, cb->v,
+                       ds->d_rows, ds->n, first, count, bpad, (const float *)dwmin,
+                       (const uint64_t *)dwmask, (const float *)dtau, d_keys, e->d_stats);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // keys[count] <- exact nearest row per sample, FIRST tie rule, local shard
 static int scan_keys_top1(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
                           uint64_t *d_keys) {
@@ -393,6 +460,9 @@ static int scan_keys_top1(somhip_codebook *cb, somhip_dataset *ds, int64_t first
                        ds->d_rows, ds->n, ds->d, cb->v.d4, first, count, (float4 *)xt);
   }
   HIPCHK(hipGetLastError());
+  e->samples_searched += (uint64_t)count;
+  if (e->scan_mode == SOMHIP_SCAN_MFMA && count >= MFMA_MIN_SAMPLES && cb->v.n >= 64)
+    return scan_keys_mfma(cb, ds, first, count, (const float4 *)xt, nsb, d_keys);
   {
     LaunchTimer t(e, KID_SCAN_EXACT);
     dim3 grid((unsigned)nsb, (unsigned)((cb->v.ngroups + 3) / 4));
@@ -463,7 +533,7 @@ extern "C" int somhip_find_winners(somhip_codebook *cb, somhip_dataset *ds, int6
   const bool knn_rule = (tie == SOMHIP_TIE_KNN) && knn >= 2;
   if (!knn_rule && knn != 1) return fail("somhip_find_winners: knn > 1 needs SOMHIP_TIE_KNN");
   if (ds->d_mask && knn_rule) return fail("somhip_find_winners: k-NN with masked samples is not implemented");
-  const int64_t CH = 16384;
+  const int64_t CH = 4096;
   const int KK = knn == 1 ? 1 : knn == 2 ? 2 : knn <= 4 ? 4 : 8;
   void *dk;
   CHK(engine_scratch(e, 3, sizeof(uint64_t) * (size_t)std::min(CH, count) * KK, &dk));
@@ -601,7 +671,7 @@ static int som_update_run(somhip_codebook *cb, somhip_dataset *ds, int64_t data_
   const bool G = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN, M = ds->d_mask != nullptr;
   constexpr int QW = 16, TB = 64;
   void *dbxy;
-  CHK(engine_scratch(e, 5, sizeof(int2) * (size_t)count, &dbxy));
+  CHK(engine_scratch(e, 8, sizeof(int2) * (size_t)count, &dbxy));
   {
     LaunchTimer t(e, KID_DECODE);
     hipLaunchKernelGGL(k_decode_winners, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream,

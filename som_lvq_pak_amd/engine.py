@@ -44,6 +44,15 @@ class Engine:
     def stream(self):
         return self.lib.somhip_engine_stream(self.h)
 
+    def set_scan_mode(self, mode):
+        """'direct' or 'mfma' (see include/somhip.h)"""
+        check(self.lib.somhip_engine_set_scan_mode(self.h, {"direct": 0, "mfma": 1}[mode]))
+
+    def scan_stats(self):
+        out = (C.c_uint64 * 4)()
+        check(self.lib.somhip_scan_stats(self.h, out))
+        return {"groups": out[0], "rows": out[1], "max_groups_per_sample": out[2], "samples": out[3]}
+
     # --- timing table (HIP events on the engine's stream) ---
     def timing(self, on=True):
         check(self.lib.somhip_timing_enable(self.h, int(on)))

@@ -288,3 +288,73 @@ def test_errors(eng, E):
         E.som_train(cb2, ds2, 10, 0.1, 1.0)
     with pytest.raises(Exception, match="labels"):
         E.lvq_train(cb2, ds2, 1, 10, 0.1)
+
+
+# --------------------------------------------------------------------------- MFMA pre-filter + exact re-rank
+@pytest.mark.parametrize("n,d,m", [(64, 4, 32), (200, 20, 333), (1000, 130, 257), (4096, 64, 512),
+                                    (777, 33, 129), (130, 512, 64)])
+def test_mfma_prefilter_equals_direct_scan(eng, E, oracle, n, d, m):
+    x, _ = synth(n + d, m, d)
+    rs = np.random.RandomState(n)
+    codes = (x[rs.randint(0, m, n)] + 0.25 * rs.standard_normal((n, d))).astype(np.float32)
+    cb, ds = E.Codebook(eng, codes), E.Dataset(eng, x)
+    oi, od, _ = oracle.winners(codes, x)
+    out = {}
+    for mode in ("direct", "mfma"):
+        eng.set_scan_mode(mode)
+        out[mode] = E.find_winners(cb, ds)
+    eng.set_scan_mode("mfma")
+    for mode in ("direct", "mfma"):
+        gi, gd, _ = out[mode]
+        assert np.array_equal(gi, oi), mode
+        assert np.array_equal(bits(gd), bits(od)), mode
+
+
+def test_mfma_prefilter_adversarial(eng, E, oracle):
+    """cases built to break a GEMM-form argmin: exact ties (duplicated rows -> lowest index
+    must win), rows one ulp apart, a large common offset (cancellation in ||c||^2 - 2xc),
+    a codebook of a few tight clusters (many near-candidates)."""
+    rs = np.random.RandomState(9)
+    d = 48
+    base, _ = synth(3, 300, d)
+    cases = []
+    # exact duplicates, in shuffled positions
+    dup = np.concatenate([base[:100], base[:100], base[:100]], axis=0)[rs.permutation(300)]
+    cases.append(("duplicates", dup, base[100:260]))
+    # one-ulp neighbours
+    near = base[:128].copy()
+    near2 = near.copy()
+    near2[:, 7] = np.nextafter(near2[:, 7], np.float32(np.inf))
+    cases.append(("one_ulp", np.concatenate([near2, near], axis=0), base[128:288] * np.float32(1.0)))
+    # large offset: norms ~ 1e4, distances ~ 1e2
+    off = (base + np.float32(1500.0)).astype(np.float32)
+    cases.append(("offset", off[:200], off[100:300]))
+    # tight clusters
+    cent = base[:5]
+    cl = (cent[rs.randint(0, 5, 640)] + 1e-3 * rs.standard_normal((640, d))).astype(np.float32)
+    cases.append(("clusters", cl, (cent[rs.randint(0, 5, 192)] + 1e-3 * rs.standard_normal((192, d))).astype(np.float32)))
+    # samples that ARE code rows (distance exactly 0, several zero ties)
+    cases.append(("zeros", dup, dup[:96]))
+    eng.set_scan_mode("mfma")
+    for name, codes, x in cases:
+        cb, ds = E.Codebook(eng, codes), E.Dataset(eng, x)
+        gi, gd, _ = E.find_winners(cb, ds)
+        oi, od, _ = oracle.winners(codes, x)
+        assert np.array_equal(gi, oi), name
+        assert np.array_equal(bits(gd), bits(od)), name
+    st = eng.scan_stats()
+    assert st["rows"] >= st["groups"] >= 1
+
+
+def test_som_minibatch_mfma_and_direct_same_run(eng, E, oracle):
+    x, _ = synth(61, 1500, 40)
+    ini = oracle.randinit(x, 20, 13, 6)
+    oc, oi, od = oracle.som_train(ini, 20, 13, 3, 1, x, 3000, 0.05, 7.0, batch=256)
+    for mode in ("direct", "mfma"):
+        eng.set_scan_mode(mode)
+        cb, ds = E.Codebook(eng, ini, 3, 1, 20, 13), E.Dataset(eng, x)
+        ti, td = E.som_train(cb, ds, 3000, 0.05, 7.0, batch=256)
+        assert np.array_equal(ti, oi), mode
+        assert np.array_equal(bits(td), bits(od)), mode
+        assert np.array_equal(bits(cb.download()), bits(oc)), mode
+    eng.set_scan_mode("mfma")

@@ -23,6 +23,8 @@ def main():
     cb = E.Codebook(eng, codes, E.TOPOL_HEXA, E.NEIGH_BUBBLE, xdim, ydim)
     ds = E.Dataset(eng, x)
     eng.timing(True)
+    import os
+    eng.set_scan_mode(os.environ.get("SCAN", "mfma"))
     for label, kw, iters in (("minibatch r=big", dict(radius=xdim / 2.0, batch=B), 2 * B),
                              ("minibatch r=3", dict(radius=3.0, batch=B), 2 * B),
                              ("online r=big", dict(radius=xdim / 2.0, batch=1), 256),
@@ -46,6 +48,7 @@ def main():
         eng.sync()
         dt = time.time() - t0
         print("%-26s %8.1f vec/s  %.2f us/iter" % (label, iters / dt, 1e6 * dt / iters))
+    print("scan stats", eng.scan_stats())
     cbytes = n * dim * 4
     print("codebook bytes %.1f MiB, scan flops/sample (3*N*d) %.1f M" % (cbytes / 2**20, 3 * n * dim / 1e6))
 
