@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--cpu-vectors", type=int, default=400,
                     help="vectors the CPU reference trains on for cpu_baseline (0 = skip)")
     ap.add_argument("--eval-vectors", type=int, default=8192)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path with ranks sharing GPUs (keys staged through the host)")
     ap.add_argument("--online-vectors", type=int, default=-1,
                     help="also run the reference-exact online engine (batch 1) over the same schedule; "
                          "-1 = the whole K*batch run when it is <= 600k vectors, 0 = skip")
@@ -72,11 +74,15 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU path")
+    local = local % torch.cuda.device_count()          # gloo rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     B, K, W = a.batch, a.steps, a.warmup
     xdim, ydim, d = a.xdim, a.ydim, a.dim
@@ -84,18 +90,24 @@ def main():
     radius = a.radius if a.radius is not None else max(xdim, ydim) / 2.0
     length = K * B
 
-    # ---- synthetic data, identical on every rank, resident in HBM before timing ----
+    # ---- synthetic data, identical on every rank, resident in HBM before timing.  Generated in
+    # fixed chunks with per-chunk seeds so that the stream does not depend on K, W or the batch size.
+    ncent, chunk = 256, 65536
     g = torch.Generator(device=dev)
     g.manual_seed(3456)
-    ncent = 256
     centres = 4.0 * torch.randn(ncent, d, generator=g, device=dev)
-    nvec = (K + W) * B
-    assign = torch.randint(0, ncent, (nvec,), generator=g, device=dev)
-    data = centres[assign] + torch.randn(nvec, d, generator=g, device=dev)
-    data = data.contiguous()
-    lo, hi = data.min(0).values, data.max(0).values
+    nvec = K * B
+    data = torch.empty(nvec, d, device=dev)
+    for c0 in range(0, nvec, chunk):
+        g.manual_seed(3456 + 1 + c0 // chunk)
+        m = min(chunk, nvec - c0)
+        assign = torch.randint(0, ncent, (chunk,), generator=g, device=dev)[:m]
+        data[c0:c0 + m] = centres[assign] + torch.randn(chunk, d, generator=g, device=dev)[:m]
+    g.manual_seed(3455)
+    first = data[:min(nvec, chunk)]
+    lo, hi = first.min(0).values, first.max(0).values
     init = (lo + (hi - lo) * torch.rand(N, d, generator=g, device=dev)).cpu().numpy()   # randinit-like
-    del centres, assign
+    del centres, assign, first
     torch.cuda.synchronize()
 
     eng = E.Engine(local)
@@ -128,7 +140,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warmup on the first W batches, then restore the initial codebook ----
-    for k in range(W):
+    for k in range(min(W, K)):
         step(k * B, k * B, B, max(W, 1) * B)
     eng.sync()
     cb.upload(init[r0:r1])
@@ -136,23 +148,25 @@ def main():
     # ---- timed region: one complete training run of K*B vectors ----
     eng.timing(True)
     eng.timing_reset()
+    stats_before = eng.scan_stats()
     barrier()
     t0 = time.perf_counter()
     for k in range(K):
-        step(k * B, W * B + k * B, B, length)
+        step(k * B, k * B, B, length)
     barrier()
     t1 = time.perf_counter()
     eng.timing(False)
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     table = eng.timing_table()
+    stats_after = eng.scan_stats()
 
     # ---- final qerror on the first eval vectors of the training stream ----
     ne = min(a.eval_vectors, nvec)
-    ek = gshard.winner_keys(W * B, ne)
+    ek = gshard.winner_keys(0, ne)
     eng.sync()
     sharded.allreduce_min_keys(ek)
     diffs, _ = sharded.unpack_keys(ek.cpu().numpy())
@@ -165,12 +179,12 @@ def main():
         nonl = min(nonl, length)
         cb.upload(init[r0:r1])
         eng.sync()
-        p = SomParams(length, a.alpha, radius, E.ALPHA_LINEAR, 0, 0, 1, 0, nonl, W * B)
+        p = SomParams(length, a.alpha, radius, E.ALPHA_LINEAR, 0, 0, 1, 0, nonl, 0)
         t2 = time.perf_counter()
         E.check(lib.somhip_som_train(cb.h, ds.h, C.byref(p), None, None))
         eng.sync()
         t3 = time.perf_counter()
-        ek = gshard.winner_keys(W * B, ne)
+        ek = gshard.winner_keys(0, ne)
         eng.sync()
         d2, _ = sharded.unpack_keys(ek.cpu().numpy())
         q2 = float(E.qerror_sum(d2) / np.float32(ne))
@@ -182,25 +196,40 @@ def main():
     out = None
     if rank == 0:
         value = K * B / elapsed
-        # dominant kernel of the timed region, by total time
-        kname, (kl, kms) = max(table.items(), key=lambda kv: kv[1][1])
+        # rooflines of the kernels of the timed region; the dominant one (by total time) is reported
         n_local = r1 - r0
-        avg_s = (kms / max(kl, 1)) * 1e-3
-        if kname == "k_scan_exact":
-            # direct-form distance: sub, mul, add per (row, sample, dim); SURVEY.md 8(d): 3*N*d per vector
-            alg = 3.0 * n_local * d * B
-            roof = {"kernel": kname, "bound": "mfma", "achieved": alg / avg_s / 1e12, "peak": PEAK_F32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": alg / avg_s / 1e12 / PEAK_F32_TFLOPS, "traffic": None,
-                    "launches": kl, "avg_launch_ms": avg_s * 1e3,
-                    "note": "exact fp32 direct-form scan on the vector ALU (no FMA allowed: 1 flop/instr, "
-                            "ceiling = peak/2); priced against the fp32 matrix/vector peak"}
-        else:
-            # streaming kernels: every code row read once (+ written where it changed) per launch
-            alg = 4.0 * n_local * d
-            roof = {"kernel": kname, "bound": "hbm", "achieved": alg / avg_s / 1e9, "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": alg / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
-                    "launches": kl, "avg_launch_ms": avg_s * 1e3,
-                    "note": "algorithmic bytes = one read of the local codebook shard per launch"}
+        bpad = ((B + 31) // 32) * 32
+        rows_upd = stats_after["row_updates"] - stats_before["row_updates"]
+
+        def roof_of(kname):
+            kl, kms = table[kname]
+            avg_s = (kms / max(kl, 1)) * 1e-3
+            base = {"kernel": kname, "launches": kl, "avg_launch_ms": avg_s * 1e3, "traffic": None}
+            if kname == "k_dist_mfma":
+                alg = 2.0 * n_local * d * bpad                  # 2*N*d per vector, GEMM form
+                note = "fp32 MFMA (v_mfma_f32_32x32x2_f32) distance GEMM, 2*N*d flop per vector"
+            elif kname == "k_scan_exact":
+                alg = 3.0 * n_local * d * B                     # direct form: sub, mul, add
+                note = ("direct-form fp32 scan on the vector ALU, 3*N*d flop per vector; no FMA allowed, so its "
+                        "ceiling is half the fp32 peak")
+            elif kname == "k_som_update_run":
+                alg = 3.0 * d * rows_upd / max(kl, 1)           # c += a*(x-c): sub, mul, add per element
+                note = ("in-order neighbourhood update on the vector ALU: 3*d flop per (row, iteration) update, "
+                        "%.0f row updates per launch counted by the kernel; no FMA allowed (ceiling = half the "
+                        "fp32 peak); priced against the fp32 matrix/vector peak" % (rows_upd / max(kl, 1)))
+            else:
+                alg = 4.0 * n_local * d                         # streaming: one read of the shard per launch
+                base.update({"bound": "hbm", "achieved": alg / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": alg / avg_s / 1e9 / PEAK_HBM_GBS,
+                             "note": "algorithmic bytes = one read of the local codebook shard per launch"})
+                return base
+            base.update({"bound": "mfma", "achieved": alg / avg_s / 1e12, "peak": PEAK_F32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": alg / avg_s / 1e12 / PEAK_F32_TFLOPS, "note": note})
+            return base
+
+        ranked = sorted((k for k in table if table[k][0]), key=lambda k: -table[k][1])
+        roof = roof_of(ranked[0])
+        roof_other = [roof_of(k) for k in ranked[1:3]]
         cpu = cpu_baseline(a, init, data, xdim, ydim, d, radius) if (world == 1 and a.cpu_vectors > 0) else None
         out = {
             "metric": "training_vectors_per_sec", "value": value, "unit": "vectors/s",
@@ -216,8 +245,15 @@ def main():
                        "parallelism": "codebook rows sharded /%d, all-reduce(MIN) of (dist,idx) keys" % world
                        if world > 1 else "single GPU"},
             "roofline": roof,
+            "roofline_other": roof_other,
             "cpu_baseline": cpu,
             "online_exact": online,
+            "rerank_stats": {"samples": stats_after["samples"] - stats_before["samples"],
+                             "groups_per_sample": (stats_after["groups"] - stats_before["groups"])
+                             / max(stats_after["samples"] - stats_before["samples"], 1),
+                             "rows_per_sample": (stats_after["rows"] - stats_before["rows"])
+                             / max(stats_after["samples"] - stats_before["samples"], 1),
+                             "max_groups_per_sample": stats_after["max_groups_per_sample"]},
             "kernels_ms": {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in table.items() if v[0]},
         }
         print(json.dumps(out))

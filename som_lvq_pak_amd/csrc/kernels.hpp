@@ -91,6 +91,18 @@ __device__ __forceinline__ float lattice_sq(int topol, int bx, int by, int tx, i
   return static_cast<float>(static_cast<double>(r) + t);
 }
 
+// The same value without fp64, valid when both map sides are <= 1024: every intermediate
+// (dx +- 0.5, dx^2, 0.75 dy^2, their sum) is then a multiple of 0.25 below 2^22 and exactly
+// representable in fp32, so the reference's mixed float/double expression and this one
+// round nowhere and agree bit for bit.
+__device__ __forceinline__ float lattice_sq_small(int topol, int bx, int by, int tx, int ty) {
+  float dx = static_cast<float>(bx - tx);
+  const float dy = static_cast<float>(by - ty);
+  if (topol == 4 /*rect*/) return dx * dx + dy * dy;
+  if ((by - ty) & 1) dx += (by & 1) ? 0.5f : -0.5f;
+  return dx * dx + 0.75f * (dy * dy);
+}
+
 // gaussian_adapt's factor, som_rout.c:539-542
 __device__ __forceinline__ float gaussian_alpha(float lat_sq, float radius, float alpha) {
   float dd = static_cast<float>(sqrt(static_cast<double>(lat_sq)));
@@ -512,75 +524,6 @@ __global__ __launch_bounds__(256, 2) void k_dist_mfma(CbView cb, const float4 *_
 }
 
 // =====================================================================================
-// K2r: exact re-rank.  One wave per sample: global minimum of the group minima, then
-// for every group within tau of it, the masked rows' distances with the reference's
-// arithmetic (lane = row, dims in order, sub/mul/add), exact (distance, index) minimum.
-// stats[0] += groups re-ranked, stats[1] += rows re-ranked, stats[2] = max groups/sample.
-// =====================================================================================
-__global__ __launch_bounds__(256) void k_rerank(CbView cb, const float *__restrict__ rows,
-                                                int64_t n_rows, int64_t first, int64_t count,
-                                                int64_t bpad, const float *__restrict__ wmin,
-                                                const uint64_t *__restrict__ wmask,
-                                                const float *__restrict__ tau,
-                                                uint64_t *__restrict__ keys,
-                                                unsigned long long *__restrict__ stats) {
-  const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (b >= count) return;
-  float m = 3.4e38f;
-  for (int64_t g = lane; g < cb.ngroups; g += WAVE) m = fminf(m, wmin[g * bpad + b]);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off, WAVE));
-  const float thr = m + tau[b];
-  const float *x = rows + ((first + b) % n_rows) * cb.d;
-  const bool vec = (cb.d & 3) == 0;
-  uint64_t best = KEY_NONE;
-  unsigned ngroups_done = 0, nrows_done = 0;
-  for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
-    const int64_t gl = gb + lane;
-    const bool q = gl < cb.ngroups && wmin[gl * bpad + b] <= thr;
-    uint64_t ball = __ballot(q);
-    while (ball) {
-      const int t = __builtin_ctzll(ball);
-      ball &= ball - 1;
-      const int64_t g = gb + t;
-      const uint64_t mask = wmask[g * bpad + b];
-      // lane -> code row of the group: the mask bit of row rr is
-      //   half = (rr>>2)&1, i = rr>>5, r = (rr&3) + 4*((rr&31)>>3)  -> bit 32*half + 16*i + r
-      const int rr = lane;
-      const int hbit = (rr >> 2) & 1, ib = rr >> 5, rb = (rr & 3) + 4 * ((rr & 31) >> 3);
-      const bool mine = (mask >> (32 * hbit + 16 * ib + rb)) & 1ull;
-      const int64_t row = g * WAVE + lane;
-      float acc = 0.0f;
-      for (int qq = 0; qq < cb.d4; qq++) {
-        const float4 c = *tile_ptr(cb, g, qq, lane);
-        const float4 xv = vec ? reinterpret_cast<const float4 *>(x)[qq]
-                              : make_float4(qq * 4 + 0 < cb.d ? x[qq * 4 + 0] : 0.f,
-                                            qq * 4 + 1 < cb.d ? x[qq * 4 + 1] : 0.f,
-                                            qq * 4 + 2 < cb.d ? x[qq * 4 + 2] : 0.f,
-                                            qq * 4 + 3 < cb.d ? x[qq * 4 + 3] : 0.f);
-        acc = sq_acc(acc, c.x, xv.x);
-        acc = sq_acc(acc, c.y, xv.y);
-        acc = sq_acc(acc, c.z, xv.z);
-        acc = sq_acc(acc, c.w, xv.w);
-      }
-      const bool ok = mine && row < cb.n;
-      const uint64_t k = ok ? make_key(acc, static_cast<uint32_t>(row + cb.row_offset)) : KEY_NONE;
-      best = k < best ? k : best;
-      ngroups_done++;
-      nrows_done += __popcll(mask);
-    }
-  }
-  best = wave_min_u64(best);
-  if (lane == 0) {
-    keys[b] = best;
-    atomicAdd(stats + 0, static_cast<unsigned long long>(ngroups_done));
-    atomicAdd(stats + 1, static_cast<unsigned long long>(nrows_done));
-    atomicMax(stats + 2, static_cast<unsigned long long>(ngroups_done));
-  }
-}
-
-// =====================================================================================
 // K1m: masked variant, one sample per launch column (rare path: data with 'x'
 // components, lvq_pak.c:65-69).  mask is wave-uniform per component.
 // =====================================================================================
@@ -611,6 +554,17 @@ __global__ __launch_bounds__(256) void k_scan_masked(CbView cb, const float *__r
   k = wave_min_u64(k);
   if (lane == 0)
     atomicMin(reinterpret_cast<unsigned long long *>(keys + smp), static_cast<unsigned long long>(k));
+}
+
+template <bool VEC>
+__device__ __forceinline__ float4 load_x4(const float *__restrict__ xr, int q, int d) {
+  if (VEC) return reinterpret_cast<const float4 *>(xr)[q];     // wave-uniform
+  float4 x;
+  x.x = q * 4 + 0 < d ? xr[q * 4 + 0] : 0.f;
+  x.y = q * 4 + 1 < d ? xr[q * 4 + 1] : 0.f;
+  x.z = q * 4 + 2 < d ? xr[q * 4 + 2] : 0.f;
+  x.w = q * 4 + 3 < d ? xr[q * 4 + 3] : 0.f;
+  return x;
 }
 
 // =====================================================================================
@@ -645,11 +599,18 @@ __global__ void k_decode_winners(const uint64_t *__restrict__ keys, const StepSc
 // (lvq_pak.c:339-351) for iterations batch_start .. batch_start+count-1, applied to
 // every code row in iteration order.  One lane = one code row, QW chunks (4*QW dims) of
 // it held in registers across the whole run, so each touched row is read and written
-// once per run whatever the batch size.  A workgroup = 4 row groups x one slice of
-// 4*QW dims; the samples' slice is staged through LDS in tiles of TB samples (one
-// coalesced pass, shared by the 4 waves, read back as broadcasts).  Tiles and samples
-// whose neighbourhood cannot reach the workgroup's / wave's units are skipped on a
-// bounding-box test with the per-iteration reach computed on the host.
+// once per run whatever the batch size.
+//
+// A workgroup = ONE row group (64 rows) x 4 consecutive dim slices (one per wave): the
+// four waves see the same membership pattern, so they stay balanced between barriers.
+// Samples are processed in tiles of TB:
+//   1. per-sample scalars -> LDS; samples whose neighbourhood cannot reach the group's
+//      lattice rows are dropped on the host-computed reach (whole tile skipped if none);
+//   2. each wave decides membership of a quarter of the tile's samples once for the whole
+//      workgroup: 64-bit lane mask per sample (bubble) or per-lane alpha (gaussian);
+//   3. the slices of the samples that touch the group are staged into LDS (coalesced);
+//   4. every wave walks the tile in iteration order: one LDS word tells it whether and
+//      which lanes update, x comes back as broadcast reads.
 // =====================================================================================
 template <int QW, int TB, bool GAUSS, bool MASKED>
 __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *__restrict__ rows,
@@ -657,123 +618,141 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
                                                         int64_t n_rows, int64_t data_first,
                                                         int64_t count,
                                                         const int2 *__restrict__ bxy,
-                                                        const StepScalars *__restrict__ sc) {
-  __shared__ float4 xs[TB][QW];
-  __shared__ uint32_t ms[MASKED ? TB : 1][MASKED ? QW : 1];   // 4 mask bytes per chunk
-  __shared__ int s_bx[TB], s_by[TB], s_reach[TB], s_hit[TB];
-  __shared__ float s_alpha[TB], s_thr[TB];
+                                                        const StepScalars *__restrict__ sc,
+                                                        unsigned long long *__restrict__ member_count) {
+  constexpr int BQ = 4 * QW;                          // chunks per workgroup
+  constexpr int ST = 256;                             // samples per super-tile (one per thread)
+  __shared__ float4 xs[TB][BQ];
+  __shared__ uint32_t ms[MASKED ? TB : 1][MASKED ? BQ : 1];   // 4 mask bits per chunk
+  __shared__ float s_ga[GAUSS ? TB : 1][GAUSS ? WAVE : 1];    // gaussian: per-lane alpha
+  __shared__ unsigned long long s_mask[TB];
+  __shared__ unsigned long long s_hitbits[ST / WAVE];
+  __shared__ long long s_xoff[ST];                    // element offset of the sample's row
+  __shared__ int s_bx[ST], s_by[ST];
+  __shared__ float s_alpha[ST], s_thr[ST];
+  __shared__ int s_list[TB], s_nlist;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave;
-  const int q0 = blockIdx.y * QW;
+  const int64_t g = blockIdx.x;
+  const int qblk = blockIdx.y * BQ;
+  const int q0 = qblk + wave * QW;
   const uint32_t xdim = static_cast<uint32_t>(cb.xdim);
-  const bool wave_on = g < cb.ngroups;
   const int64_t row = g * WAVE + lane;
-  const bool live = wave_on && row < cb.n;
+  const bool live = row < cb.n;
   const uint32_t grow = static_cast<uint32_t>(row + cb.row_offset);
   const int tx = static_cast<int>(grow % xdim), ty = static_cast<int>(grow / xdim);
-
-  // unit rows (lattice y) this workgroup / this wave can touch
-  const int64_t blk_r0 = static_cast<int64_t>(blockIdx.x) * 4 * WAVE;
-  const int64_t blk_r1 = (blk_r0 + 4 * WAVE < cb.n ? blk_r0 + 4 * WAVE : cb.n) - 1;
-  const int blk_ty0 = static_cast<int>(static_cast<uint32_t>(blk_r0 + cb.row_offset) / xdim);
-  const int blk_ty1 = static_cast<int>(static_cast<uint32_t>(blk_r1 + cb.row_offset) / xdim);
-  int w_ty0 = 0, w_ty1 = -1;
-  if (wave_on) {
-    int64_t r0 = g * WAVE, r1 = (r0 + WAVE < cb.n ? r0 + WAVE : cb.n) - 1;
-    w_ty0 = static_cast<int>(static_cast<uint32_t>(r0 + cb.row_offset) / xdim);
-    w_ty1 = static_cast<int>(static_cast<uint32_t>(r1 + cb.row_offset) / xdim);
-  }
-  w_ty0 = __builtin_amdgcn_readfirstlane(w_ty0);
-  w_ty1 = __builtin_amdgcn_readfirstlane(w_ty1);
+  const int64_t r_last = (g * WAVE + WAVE < cb.n ? g * WAVE + WAVE : cb.n) - 1;
+  const int g_ty0 = static_cast<int>(static_cast<uint32_t>(g * WAVE + cb.row_offset) / xdim);
+  const int g_ty1 = static_cast<int>(static_cast<uint32_t>(r_last + cb.row_offset) / xdim);
+  const bool small_map = cb.xdim <= 1024 && g_ty1 < 1024;
+  const bool vec = (cb.d & 3) == 0;
 
   float4 c[QW];
 #pragma unroll
   for (int j = 0; j < QW; j++)
-    c[j] = (wave_on && q0 + j < cb.d4) ? *tile_ptr(cb, g, q0 + j, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    c[j] = (q0 + j < cb.d4) ? *tile_ptr(cb, g, q0 + j, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
   bool dirty = false;
-  const bool vec = (cb.d & 3) == 0;
+  unsigned long long members = 0;
 
-  for (int64_t t0 = 0; t0 < count; t0 += TB) {
-    const int tb = static_cast<int>(count - t0 < TB ? count - t0 : TB);
-    // ---- phase 1: per-sample scalars + reach test against the workgroup's unit rows
-    int hit = 0;
-    if (tid < TB) {
-      int bx = -1, by = -1, reach = -1;
+  for (int64_t T0 = 0; T0 < count; T0 += ST) {
+    // ---- 1. scalars of 256 samples (one global round trip) + reach test
+    {
+      int bx = -1, by = -1, hit = 0;
       float al = 0.f, th = 0.f;
-      if (tid < tb) {
-        const int2 w = bxy[t0 + tid];
-        const StepScalars s = sc[t0 + tid];
-        bx = w.x; by = w.y; reach = s.reach; al = s.alpha; th = s.thresh;
-        hit = (bx >= 0) && (by + reach >= blk_ty0) && (by - reach <= blk_ty1);
+      const int64_t b = T0 + tid;
+      if (b < count) {
+        const int2 w = bxy[b];
+        const StepScalars s = sc[b];
+        bx = w.x; by = w.y; al = s.alpha; th = s.thresh;
+        hit = (bx >= 0) && (by + s.reach >= g_ty0) && (by - s.reach <= g_ty1);
+        if (hit) s_xoff[tid] = ((data_first + b) % n_rows) * cb.d;
       }
-      s_bx[tid] = bx; s_by[tid] = by; s_reach[tid] = reach; s_alpha[tid] = al; s_thr[tid] = th;
-      s_hit[tid] = hit;
-    }
-    if (!__syncthreads_or(hit)) continue;      // nothing in this tile reaches us (uniform)
-    // ---- phase 2: the tile's slice of the samples -> LDS
-    for (int e = tid; e < TB * QW; e += 256) {
-      const int s = e / QW, j = e % QW, q = q0 + j;
-      if (s < tb && s_hit[s] && q < cb.d4) {
-        const int64_t r = (data_first + t0 + s) % n_rows;
-        const float *xr = rows + r * cb.d;
-        float4 x;
-        if (vec) x = reinterpret_cast<const float4 *>(xr)[q];
-        else {
-          x.x = q * 4 + 0 < cb.d ? xr[q * 4 + 0] : 0.f;
-          x.y = q * 4 + 1 < cb.d ? xr[q * 4 + 1] : 0.f;
-          x.z = q * 4 + 2 < cb.d ? xr[q * 4 + 2] : 0.f;
-          x.w = q * 4 + 3 < cb.d ? xr[q * 4 + 3] : 0.f;
-        }
-        xs[s][j] = x;
-        if (MASKED) {
-          const uint8_t *m = mask + r * cb.d;
-          uint32_t mm = 0;
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            if (q * 4 + u >= cb.d || m[q * 4 + u] != 0) mm |= 1u << u;
-          ms[s][j] = mm;
-        }
-      }
+      s_bx[tid] = bx; s_by[tid] = by; s_alpha[tid] = al; s_thr[tid] = th;
+      const unsigned long long hb = __ballot(hit);
+      if (lane == 0) s_hitbits[wave] = hb;
     }
     __syncthreads();
-    // ---- phase 3: the tile's updates, in iteration order
-    if (wave_on) {
-      for (int s = 0; s < tb; s++) {
-        if (!s_hit[s]) continue;
-        const int bx = s_bx[s], by = s_by[s], reach = s_reach[s];
-        if (by + reach < w_ty0 || by - reach > w_ty1) continue;
-        const float lsq = lattice_sq(cb.topol, bx, by, tx, ty);
-        float a;
-        bool member;
-        if (GAUSS) { a = gaussian_alpha(lsq, s_thr[s], s_alpha[s]); member = live; }
-        else { a = s_alpha[s]; member = live && (lsq <= s_thr[s]); }
-        if (!__any(member)) continue;
-        if (member) {
-          dirty = true;
+    for (int t0 = 0; t0 < ST && T0 + t0 < count; t0 += TB) {
+      // hit bits of this sub-tile (TB divides 64)
+      const unsigned long long hbits = (s_hitbits[t0 >> 6] >> (t0 & 63)) & ((TB == 64) ? ~0ull : ((1ull << TB) - 1));
+      if (hbits == 0) continue;                          // uniform
+      // ---- 2. membership, once per (row group, sample)
+      for (int s = wave; s < TB; s += 4) {
+        unsigned long long m = 0;
+        if ((hbits >> s) & 1ull) {
+          const int ss = t0 + s;
+          const float lsq = small_map ? lattice_sq_small(cb.topol, s_bx[ss], s_by[ss], tx, ty)
+                                      : lattice_sq(cb.topol, s_bx[ss], s_by[ss], tx, ty);
+          bool member;
+          if (GAUSS) { s_ga[s][lane] = gaussian_alpha(lsq, s_thr[ss], s_alpha[ss]); member = live; }
+          else member = live && (lsq <= s_thr[ss]);
+          m = __ballot(member);
+        }
+        if (lane == 0) s_mask[s] = m;
+        if (blockIdx.y == 0) members += __popcll(m);
+      }
+      __syncthreads();
+      // compact list of the samples that touch this group, in iteration order
+      if (wave == 0) {
+        const bool on = lane < TB && s_mask[lane < TB ? lane : 0] != 0;
+        const unsigned long long bal = __ballot(on);
+        if (on) s_list[__popcll(bal & ((1ull << lane) - 1))] = lane;
+        if (lane == 0) s_nlist = __popcll(bal);
+      }
+      __syncthreads();
+      const int nlist = s_nlist;
+      if (nlist == 0) continue;                          // uniform
+      // ---- 3. slices of those samples -> LDS
+      for (int e = tid; e < nlist * BQ; e += 256) {
+        const int i = e / BQ, j = e % BQ, q = qblk + j;
+        if (q < cb.d4) {
+          const long long xo = s_xoff[t0 + s_list[i]];
+          const float *xr = rows + xo;
+          xs[i][j] = vec ? reinterpret_cast<const float4 *>(xr)[q] : load_x4<false>(xr, q, cb.d);
+          if (MASKED) {
+            const uint8_t *mk = mask + xo;
+            uint32_t mm = 0;
 #pragma unroll
-          for (int j = 0; j < QW; j++) {
-            const float4 n = adapt4(c[j], xs[s][j], a);
-            if (MASKED) {
-              const uint32_t mm = ms[s][j];
-              if (!(mm & 1u)) c[j].x = n.x;
-              if (!(mm & 2u)) c[j].y = n.y;
-              if (!(mm & 4u)) c[j].z = n.z;
-              if (!(mm & 8u)) c[j].w = n.w;
-            } else {
-              c[j] = n;      // padding dims: x pad = 0, c pad = 0 -> stays 0
+            for (int u = 0; u < 4; u++)
+              if (q * 4 + u >= cb.d || mk[q * 4 + u] != 0) mm |= 1u << u;
+            ms[i][j] = mm;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- 4. the updates, in iteration order
+      if (q0 < cb.d4) {
+        for (int i = 0; i < nlist; i++) {
+          const int s = s_list[i];
+          if ((s_mask[s] >> lane) & 1ull) {
+            const float a = GAUSS ? s_ga[s][lane] : s_alpha[t0 + s];
+            dirty = true;
+#pragma unroll
+            for (int j = 0; j < QW; j++) {
+              const float4 n = adapt4(c[j], xs[i][wave * QW + j], a);
+              if (MASKED) {
+                const uint32_t mm = ms[i][wave * QW + j];
+                if (!(mm & 1u)) c[j].x = n.x;
+                if (!(mm & 2u)) c[j].y = n.y;
+                if (!(mm & 4u)) c[j].z = n.z;
+                if (!(mm & 8u)) c[j].w = n.w;
+              } else {
+                c[j] = n;      // padding dims: x pad = 0, c pad = 0 -> stays 0
+              }
             }
           }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
+    __syncthreads();          // s_* of this super-tile are rewritten next trip
   }
   if (dirty) {
 #pragma unroll
     for (int j = 0; j < QW; j++)
       if (q0 + j < cb.d4) *tile_ptr_w(cb, g, q0 + j, lane) = c[j];
   }
+  if (blockIdx.y == 0 && member_count && lane == 0 && members) atomicAdd(member_count, members);
 }
 
 // =====================================================================================
@@ -789,17 +768,6 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
 // is branch-free (UPD / SEARCH / MASKED / VEC are compile-time) so the waits the
 // compiler places are counted, not drains.
 // =====================================================================================
-template <bool VEC>
-__device__ __forceinline__ float4 load_x4(const float *__restrict__ xr, int q, int d) {
-  if (VEC) return reinterpret_cast<const float4 *>(xr)[q];     // wave-uniform
-  float4 x;
-  x.x = q * 4 + 0 < d ? xr[q * 4 + 0] : 0.f;
-  x.y = q * 4 + 1 < d ? xr[q * 4 + 1] : 0.f;
-  x.z = q * 4 + 2 < d ? xr[q * 4 + 2] : 0.f;
-  x.w = q * 4 + 3 < d ? xr[q * 4 + 3] : 0.f;
-  return x;
-}
-
 template <bool UPD, bool SEARCH, bool MASKED, bool VEC>
 __device__ __forceinline__ void online_chunk(const CbView &cb, int64_t g, int lane, int q, float4 c,
                                              bool upd, float a, const float *__restrict__ xp,
@@ -931,6 +899,65 @@ __global__ __launch_bounds__(256) void k_som_online_step(CbView cb, const float 
     k = wave_min_u64(k);
     if (lane == 0)
       atomicMin(reinterpret_cast<unsigned long long *>(cur_slot), static_cast<unsigned long long>(k));
+  }
+}
+
+// =====================================================================================
+// K2r: exact re-rank.  One wave per sample: global minimum of the group minima, then
+// for every group within tau of it, the masked rows' distances with the reference's
+// arithmetic (lane = row, dims in order, sub/mul/add), exact (distance, index) minimum.
+// stats[0] += groups re-ranked, stats[1] += rows re-ranked, stats[2] = max groups/sample.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_rerank(CbView cb, const float *__restrict__ rows,
+                                                int64_t n_rows, int64_t first, int64_t count,
+                                                int64_t bpad, const float *__restrict__ wmin,
+                                                const uint64_t *__restrict__ wmask,
+                                                const float *__restrict__ tau,
+                                                uint64_t *__restrict__ keys,
+                                                unsigned long long *__restrict__ stats) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= count) return;
+  float m = 3.4e38f;
+  for (int64_t g = lane; g < cb.ngroups; g += WAVE) m = fminf(m, wmin[g * bpad + b]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off, WAVE));
+  const float thr = m + tau[b];
+  const float *x = rows + ((first + b) % n_rows) * cb.d;
+  const bool vec = (cb.d & 3) == 0;
+  uint64_t best = KEY_NONE;
+  unsigned ngroups_done = 0, nrows_done = 0;
+  for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
+    const int64_t gl = gb + lane;
+    const bool q = gl < cb.ngroups && wmin[gl * bpad + b] <= thr;
+    uint64_t ball = __ballot(q);
+    while (ball) {
+      const int t = __builtin_ctzll(ball);
+      ball &= ball - 1;
+      const int64_t g = gb + t;
+      const uint64_t mask = wmask[g * bpad + b];
+      // lane -> code row of the group: the mask bit of row rr is
+      //   half = (rr>>2)&1, i = rr>>5, r = (rr&3) + 4*((rr&31)>>3)  -> bit 32*half + 16*i + r
+      const int rr = lane;
+      const int hbit = (rr >> 2) & 1, ib = rr >> 5, rb = (rr & 3) + 4 * ((rr & 31) >> 3);
+      const bool mine = (mask >> (32 * hbit + 16 * ib + rb)) & 1ull;
+      const int64_t row = g * WAVE + lane;
+      // same arithmetic and order as k_scan_exact / k_som_online_step, loads pipelined
+      const float acc = vec ? online_stream<false, true, false, true, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr)
+                            : online_stream<false, true, false, false, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr);
+      const bool ok = mine && row < cb.n;
+      const uint64_t k = ok ? make_key(acc, static_cast<uint32_t>(row + cb.row_offset)) : KEY_NONE;
+      best = k < best ? k : best;
+      ngroups_done++;
+      nrows_done += __popcll(mask);
+    }
+  }
+  best = wave_min_u64(best);
+  if (lane == 0) {
+    keys[b] = best;
+    atomicAdd(stats + 0, static_cast<unsigned long long>(ngroups_done));
+    atomicAdd(stats + 1, static_cast<unsigned long long>(nrows_done));
+    atomicMax(stats + 2, static_cast<unsigned long long>(ngroups_done));
   }
 }
 

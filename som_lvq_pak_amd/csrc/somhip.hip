@@ -177,11 +177,11 @@ extern "C" int somhip_engine_set_scan_mode(somhip_engine *e, int mode) {
   e->scan_mode = mode;
   return 0;
 }
-extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[4]) {
+extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[5]) {
   unsigned long long h[4];
   HIPCHK(hipMemcpyAsync(h, e->d_stats, sizeof h, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = e->samples_searched;
+  out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = e->samples_searched; out[4] = h[3];
   return 0;
 }
 extern "C" int somhip_timing_enable(somhip_engine *e, int on) { CHK(timing_flush(e)); e->timing = on != 0; return 0; }
@@ -669,7 +669,7 @@ static int som_update_run(somhip_codebook *cb, somhip_dataset *ds, int64_t data_
                           const uint64_t *d_keys, const StepScalars *d_sc) {
   somhip_engine *e = cb->e;
   const bool G = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN, M = ds->d_mask != nullptr;
-  constexpr int QW = 16, TB = 64;
+  constexpr int QW = 8, TB = 32;
   void *dbxy;
   CHK(engine_scratch(e, 8, sizeof(int2) * (size_t)count, &dbxy));
   {
@@ -678,11 +678,11 @@ static int som_update_run(somhip_codebook *cb, somhip_dataset *ds, int64_t data_
                        d_keys, d_sc, count, cb->v.xdim, (int2 *)dbxy);
   }
   HIPCHK(hipGetLastError());
-  dim3 grid((unsigned)((cb->v.ngroups + 3) / 4), (unsigned)((cb->v.d4 + QW - 1) / QW));
+  dim3 grid((unsigned)cb->v.ngroups, (unsigned)((cb->v.d4 + 4 * QW - 1) / (4 * QW)));
   LaunchTimer t(e, KID_SOM_UPDATE_RUN);
 #define GO(GG, MM)                                                                                   \
   hipLaunchKernelGGL((k_som_update_run<QW, TB, GG, MM>), grid, dim3(256), 0, e->stream, cb->v, ds->d_rows, \
-                     (const uint8_t *)ds->d_mask, ds->n, data_first, count, (const int2 *)dbxy, d_sc)
+                     (const uint8_t *)ds->d_mask, ds->n, data_first, count, (const int2 *)dbxy, d_sc, e->d_stats + 3)
   if (G && M) GO(true, true); else if (G) GO(true, false); else if (M) GO(false, true); else GO(false, false);
 #undef GO
   HIPCHK(hipGetLastError());

@@ -48,7 +48,12 @@ def allreduce_min_keys(keys, group=None):
     import torch.distributed as dist
     keys.copy_(torch.where(keys < 0, torch.full_like(keys, KEY_MAX_I64), keys))
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
+        if keys.is_cuda and dist.get_backend(group) == "gloo":     # rehearsal path: stage through the host
+            host = keys.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
+            keys.copy_(host)
+        else:
+            dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
     return keys
 
 
