@@ -1,0 +1,654 @@
+/* paklib.c -- host library of the tools: arguments, labels, hit lists, .dat/.cod text files,
+ * the -rand shuffle, the -selfuncs registry and the epoch-level functions that hand the
+ * hot path to libsomhip.so.  Written from scratch over dense storage; file formats, flag
+ * names, messages and numerics follow SOM_PAK/LVQ_PAK 3.2 (citations: file:line in
+ * hynde/som_lvq_pak). */
+#define _GNU_SOURCE
+#include "pak.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <time.h>
+#include <unistd.h>
+
+/* ------------------------------------------------------------------ arguments */
+int verbose_level = 1;
+int use_fixed_level = 0, use_weights_level = 0;
+
+/* lvq_pak.c:583-612: linear search, the value is the next argv; OPTION2 flags take none */
+char *extract_parameter(int argc, char **argv, const char *param, int when)
+{
+  int i = 0;
+  while (i < argc && strcmp(param, argv[i]) != 0) i++;
+  if (i <= argc - 1 && when == OPTION2) return "";
+  if (i < argc - 1) return argv[i + 1];
+  if (when == ALWAYS) {
+    fprintf(stderr, "Can't find asked option %s\n", param);
+    exit(-1);
+  }
+  return NULL;
+}
+long oatoi(const char *s, long def) { return s ? atol(s) : def; }
+float oatof(const char *s, float def) { return s ? (float)atof(s) : def; }
+
+static const char *masked_string = "x";          /* datafile.h:33, -mask_str / LVQSOM_MASK_STR */
+
+int global_options(int argc, char **argv)        /* lvq_pak.c:618-660 */
+{
+  char *s = getenv("LVQSOM_MASK_STR");
+  if (s) masked_string = s;
+  s = extract_parameter(argc, argv, "-mask_str", OPTION);
+  if (s) masked_string = s;
+  if (extract_parameter(argc, argv, "-version", OPTION2))
+    fprintf(stderr, "Version: som_lvq_pak_amd (MI355X engine, libsomhip %d), file formats of SOM/LVQ_PAK 3.2\n",
+            somhip_version());
+  verbose_level = (int)oatoi(extract_parameter(argc, argv, "-v", OPTION), 1);
+  return 0;
+}
+
+const char *pak_progname(const char *argv0)      /* fileio.c:433-465: basename of argv[0] */
+{
+  const char *p = strrchr(argv0, '/');
+  return p ? p + 1 : argv0;
+}
+
+/* ------------------------------------------------------------------ labels */
+static char **label_names = NULL;                /* [0] unused: 0 = LABEL_EMPTY */
+static int label_count = 0, label_cap = 0;
+
+int find_conv_to_ind(const char *str)
+{
+  for (int i = 1; i <= label_count; i++)
+    if (strcmp(label_names[i], str) == 0) return i;
+  if (label_count + 2 > label_cap) {
+    label_cap = label_cap ? 2 * label_cap : 64;
+    label_names = realloc(label_names, sizeof(char *) * label_cap);
+  }
+  label_names[++label_count] = strdup(str);
+  return label_count;
+}
+const char *find_conv_to_lab(int ind) { return (ind >= 1 && ind <= label_count) ? label_names[ind] : NULL; }
+int number_of_labels(void) { return label_count; }
+
+struct hitlist *new_hitlist(void) { return calloc(1, sizeof(struct hitlist)); }
+void free_hitlist(struct hitlist *h) { if (h) { free(h->label); free(h->freq); free(h); } }
+long add_hit(struct hitlist *h, long label)
+{
+  long i;
+  for (i = 0; i < h->entries; i++) if (h->label[i] == label) break;
+  if (i == h->entries) {
+    if (h->entries == h->cap) {
+      h->cap = h->cap ? 2 * h->cap : 8;
+      h->label = realloc(h->label, sizeof(long) * h->cap);
+      h->freq = realloc(h->freq, sizeof(long) * h->cap);
+    }
+    h->label[i] = label; h->freq[i] = 1; h->entries++;
+    return 1;
+  }
+  long f = ++h->freq[i];
+  while (i > 0 && h->freq[i - 1] < f) {          /* strictly smaller: ties keep their order */
+    long tl = h->label[i - 1], tf = h->freq[i - 1];
+    h->label[i - 1] = h->label[i]; h->freq[i - 1] = h->freq[i];
+    h->label[i] = tl; h->freq[i] = tf;
+    i--;
+  }
+  return f;
+}
+long hitlist_label_freq(struct hitlist *h, long label)
+{
+  for (long i = 0; i < h->entries; i++) if (h->label[i] == label) return h->freq[i];
+  return 0;
+}
+
+/* ------------------------------------------------------------------ files */
+static const char *topol_names[] = {NULL, "data", "lvq", "hexa", "rect"};
+static const char *neigh_names[] = {NULL, "bubble", "gaussian"};
+
+static int id_of(const char **names, int n, const char *s)
+{
+  if (s) for (int i = 1; i < n; i++) if (strcasecmp(names[i], s) == 0) return i;
+  return 0;
+}
+
+static FILE *open_text(const char *name, const char *mode, int *is_pipe)
+{
+  size_t len = strlen(name);
+  *is_pipe = 0;
+  if (strcmp(name, "-") == 0) return mode[0] == 'r' ? stdin : stdout;
+  int gz = (len > 3 && strcmp(name + len - 3, ".gz") == 0) ||
+           (len > 2 && (strcmp(name + len - 2, ".z") == 0 || strcmp(name + len - 2, ".Z") == 0));
+  if (gz) {                                      /* fileio.c:57-200: compressed files through gzip */
+    char cmd[4096];
+    snprintf(cmd, sizeof cmd, mode[0] == 'r' ? "gzip -d -c %s" : "gzip -9 -c >%s", name);
+    *is_pipe = 1;
+    return popen(cmd, mode[0] == 'r' ? "r" : "w");
+  }
+  return fopen(name, mode);
+}
+static void close_text(FILE *fp, int is_pipe)
+{
+  if (fp == stdin || fp == stdout) return;
+  if (is_pipe) pclose(fp); else fclose(fp);
+}
+
+void clear_entry_labels(struct entries *e, long r)
+{
+  free(e->rows[r].labels);
+  e->rows[r].labels = NULL;
+  e->rows[r].num_labs = 0;
+}
+void add_entry_label(struct entries *e, long r, int label)
+{
+  struct data_entry *d = &e->rows[r];
+  d->labels = realloc(d->labels, sizeof(int) * (d->num_labs + 1));
+  d->labels[d->num_labs++] = label;
+}
+
+/* open_entries + read_entries (datafile.c:191,237) for a whole file.  Header: first
+ * non-comment line "<dim> [topol [xdim ydim neigh]]" (datafile.c:112-145).  Rows: <dim>
+ * numbers or the mask string, then labels / weight=N / fixed=X,Y (datafile.c:552-748);
+ * '#' lines and blank lines are skipped; rows with every component masked are dropped
+ * when skip_empty (datafile.c:677-686). */
+struct entries *open_entries(const char *name, int labels_needed, int skip_empty)
+{
+  int is_pipe;
+  FILE *fp = open_text(name, "r", &is_pipe);
+  if (!fp) { fprintf(stderr, "Can't open file %s", name); return NULL; }
+  struct entries *e = calloc(1, sizeof *e);
+  e->labels_needed = labels_needed;
+  char *line = NULL;
+  size_t cap = 0;
+  long lineno = 0, nalloc = 0;
+  int have_header = 0, dim = 0;
+  struct fixpoint *fixtmp = NULL;
+  int any_fixed = 0, any_weight = 0;
+  char **maskrows = NULL;
+
+  while (getline(&line, &cap, fp) >= 0) {
+    lineno++;
+    size_t L = strlen(line);
+    if (L && line[L - 1] == '\n') line[--L] = 0;
+    if (line[0] == '#') continue;
+    if (!have_header) {
+      if (sscanf(line, "%d", &dim) <= 0) {
+        fprintf(stderr, "Can't read dimension parameter in file %s", name);
+        goto fail;
+      }
+      char *save, *dup = strdup(line);
+      strtok_r(dup, " ", &save);
+      char *t = strtok_r(NULL, " ", &save);
+      char *xs = strtok_r(NULL, " ", &save), *ys = strtok_r(NULL, " ", &save), *ns = strtok_r(NULL, " ", &save);
+      e->dimension = (short)dim;
+      e->topol = (short)id_of(topol_names, 5, t);
+      e->xdim = xs ? (short)atoi(xs) : 0;
+      e->ydim = ys ? (short)atoi(ys) : 0;
+      e->neigh = (short)id_of(neigh_names, 3, ns);
+      free(dup);
+      have_header = 1;
+      continue;
+    }
+    char *save;
+    char *tok = strtok_r(line, " \r\t", &save);
+    if (!tok) continue;                          /* empty line */
+    if (e->num_entries == nalloc) {
+      nalloc = nalloc ? 2 * nalloc : 1024;
+      e->points = realloc(e->points, sizeof(float) * nalloc * dim);
+      e->rows = realloc(e->rows, sizeof(struct data_entry) * nalloc);
+      maskrows = realloc(maskrows, sizeof(char *) * nalloc);
+      fixtmp = realloc(fixtmp, sizeof(struct fixpoint) * nalloc);
+    }
+    long r = e->num_entries;
+    float *p = e->points + r * dim;
+    char *mask = NULL;
+    int maskcnt = 0;
+    for (int i = 0; i < dim; i++) {
+      if (i > 0) tok = strtok_r(NULL, " \r\t", &save);
+      if (!tok) {
+        fprintf(stderr, "load_entry: can't read entry in file %s on line %ld, component %d\n", name, lineno, i);
+        goto fail;
+      }
+      if (strcmp(tok, masked_string) == 0) {
+        if (!mask) mask = calloc(dim, 1);
+        mask[i] = 1; maskcnt++; p[i] = 0.0f;
+      } else if (sscanf(tok, "%f", &p[i]) <= 0) {
+        fprintf(stderr, "load_entry: can't read entry in file %s on line %ld, component %d\n", name, lineno, i);
+        goto fail;
+      }
+    }
+    if (maskcnt == dim && skip_empty) { free(mask); continue; }
+    struct data_entry *d = &e->rows[r];
+    memset(d, 0, sizeof *d);
+    maskrows[r] = mask;
+    fixtmp[r].xfix = fixtmp[r].yfix = -1;
+    e->num_entries++;
+    int label_found = 0;
+    while ((tok = strtok_r(NULL, " \r\t", &save)) != NULL) {
+      if (strncmp(tok, "weight=", 7) == 0) { d->weight = (short)atoi(tok + 7); any_weight = 1; }
+      else if (strncmp(tok, "fixed=", 6) == 0) {
+        char *comma = strchr(tok, ',');
+        if (!comma) { fprintf(stderr, "bad fixed point, line %ld of file %s\n", lineno, name); goto fail; }
+        fixtmp[r].xfix = (short)atoi(tok + 6);
+        fixtmp[r].yfix = (short)atoi(comma + 1);
+        any_fixed = 1;
+      } else {
+        add_entry_label(e, r, find_conv_to_ind(tok));
+        label_found++;
+      }
+    }
+    if (labels_needed && !label_found) {
+      fprintf(stderr, "Required label missing on line %ld of file %s\n", lineno, name);
+      goto fail;
+    }
+  }
+  if (!have_header) { fprintf(stderr, "Can't read file %s", name); goto fail; }
+  /* dense side arrays + row views */
+  {
+    long n = e->num_entries;
+    int any_mask = 0;
+    for (long r = 0; r < n; r++) any_mask |= maskrows[r] != NULL;
+    if (any_mask) e->masks = calloc((size_t)n * dim + 1, 1);
+    if (any_fixed) e->fixed_xy = malloc(sizeof(short) * 2 * (n + 1));
+    if (any_weight) e->weights = malloc(sizeof(short) * (n + 1));
+    for (long r = 0; r < n; r++) {
+      struct data_entry *d = &e->rows[r];
+      d->points = e->points + r * dim;
+      if (any_mask) {
+        if (maskrows[r]) { memcpy(e->masks + r * dim, maskrows[r], dim); d->mask = e->masks + r * dim; }
+      }
+      free(maskrows[r]);
+      if (any_fixed) {
+        e->fixed_xy[2 * r] = fixtmp[r].xfix; e->fixed_xy[2 * r + 1] = fixtmp[r].yfix;
+        if (fixtmp[r].xfix >= 0) d->fixed = (struct fixpoint *)(e->fixed_xy + 2 * r);
+      }
+      if (any_weight) e->weights[r] = d->weight;
+    }
+  }
+  free(maskrows); free(fixtmp); free(line);
+  close_text(fp, is_pipe);
+  return e;
+fail:
+  free(line);
+  close_text(fp, is_pipe);
+  return NULL;
+}
+
+void close_entries(struct entries *e)
+{
+  if (!e) return;
+  for (long r = 0; r < e->num_entries; r++) free(e->rows[r].labels);
+  free(e->rows); free(e->points); free(e->masks); free(e->fixed_xy); free(e->weights);
+  free(e);
+}
+
+/* write_header datafile.c:396-415, write_entry :420-447: "%g " per value, "%s " per label */
+static void write_rows(FILE *fp, struct entries *c, const char *comments)
+{
+  fprintf(fp, "%d", c->dimension);
+  if (c->topol > TOPOL_DATA) {
+    fprintf(fp, " %s", topol_names[c->topol]);
+    if (c->topol > TOPOL_LVQ) fprintf(fp, " %d %d %s", c->xdim, c->ydim, neigh_names[c->neigh] ? neigh_names[c->neigh] : "");
+  }
+  fprintf(fp, "\n");
+  if (comments) fputs(comments, fp);
+  for (long r = 0; r < c->num_entries; r++) {
+    struct data_entry *d = &c->rows[r];
+    for (int i = 0; i < c->dimension; i++)
+      if (d->mask && d->mask[i]) fprintf(fp, "%s ", masked_string);
+      else fprintf(fp, "%g ", d->points[i]);
+    for (int k = 0; k < d->num_labs; k++) {
+      if (d->labels[k] == LABEL_EMPTY) break;
+      fprintf(fp, "%s ", find_conv_to_lab(d->labels[k]));
+    }
+    fprintf(fp, "\n");
+  }
+}
+int save_entries_wcomments(struct entries *codes, const char *name, const char *comments)
+{
+  int is_pipe;
+  FILE *fp = open_text(name, "w", &is_pipe);
+  if (!fp) { fprintf(stderr, "save_entries: Can't open file '%s'\n", name); return 1; }
+  write_rows(fp, codes, comments);
+  close_text(fp, is_pipe);
+  return 0;
+}
+
+/* OLVQ1 learning-rate files, datafile.c:1030-1110: "<name up to the first '.'>.lra", one
+ * "%g" per line */
+static void lra_name(char *out, size_t n, const char *file)
+{
+  snprintf(out, n - 4, "%s", file);
+  char *dot = strchr(out, '.');
+  if (dot) *dot = 0;
+  strcat(out, ".lra");
+}
+int alpha_read(float *alpha, long noc, const char *infile)
+{
+  char nm[2048];
+  lra_name(nm, sizeof nm, infile);
+  FILE *fp = fopen(nm, "r");
+  if (!fp) { ifverbose(1) fprintf(stderr, "Can't open alpha file %s", nm); return 0; }
+  for (long i = 0; i < noc; i++)
+    if (fscanf(fp, "%g\n", &alpha[i]) < 0) { fclose(fp); return 0; }
+  fclose(fp);
+  return 1;
+}
+int alpha_write(float *alpha, long noc, const char *outfile)
+{
+  char nm[2048];
+  lra_name(nm, sizeof nm, outfile);
+  FILE *fp = fopen(nm, "w+");
+  if (!fp) { fprintf(stderr, "Can't open alpha file %s for writing", nm); return 0; }
+  for (long i = 0; i < noc; i++) fprintf(fp, "%g\n", alpha[i]);
+  fclose(fp);
+  return 0;
+}
+void invalidate_alphafile(const char *outfile)
+{
+  char nm[2048];
+  lra_name(nm, sizeof nm, outfile);
+  FILE *fp = fopen(nm, "r");
+  if (fp) {
+    ifverbose(1) fprintf(stdout, "Removing the learning rate file %s\n", nm);
+    fclose(fp);
+    if (remove(nm)) fprintf(stderr, "Can not remove %s", nm);
+  }
+}
+
+/* ------------------------------------------------------------------ RNG, shuffle */
+static unsigned long rnd_next = 1;
+void init_random(int seed) { rnd_next = seed ? (unsigned long)seed : (unsigned long)(int)time(NULL); }
+long orand(void) { rnd_next = (rnd_next * 23UL) % 100000001UL; return (long)(int)(rnd_next % 32767UL); }
+
+/* datafile.c:1152-1188: for i in order, swap slot i with slot orand() % n */
+void randomize_entry_order(struct entries *e)
+{
+  long n = e->num_entries;
+  int dim = e->dimension;
+  if (n <= 0) return;
+  long *perm = malloc(sizeof(long) * n);
+  for (long i = 0; i < n; i++) perm[i] = i;
+  for (long i = 0; i < n; i++) {
+    long j = orand() % n, t = perm[i];
+    perm[i] = perm[j]; perm[j] = t;
+  }
+  float *pts = malloc(sizeof(float) * (size_t)n * dim);
+  struct data_entry *rows = malloc(sizeof(struct data_entry) * n);
+  char *masks = e->masks ? calloc((size_t)n * dim + 1, 1) : NULL;
+  short *fx = e->fixed_xy ? malloc(sizeof(short) * 2 * (n + 1)) : NULL;
+  short *wt = e->weights ? malloc(sizeof(short) * (n + 1)) : NULL;
+  for (long i = 0; i < n; i++) {
+    long s = perm[i];
+    memcpy(pts + i * dim, e->points + s * dim, sizeof(float) * dim);
+    rows[i] = e->rows[s];
+    rows[i].points = pts + i * dim;
+    if (masks) {
+      memcpy(masks + i * dim, e->masks + s * dim, dim);
+      rows[i].mask = e->rows[s].mask ? masks + i * dim : NULL;
+    }
+    if (fx) {
+      fx[2 * i] = e->fixed_xy[2 * s]; fx[2 * i + 1] = e->fixed_xy[2 * s + 1];
+      rows[i].fixed = fx[2 * i] >= 0 ? (struct fixpoint *)(fx + 2 * i) : NULL;
+    }
+    if (wt) wt[i] = e->weights[s];
+  }
+  free(e->points); free(e->rows); free(e->masks); free(e->fixed_xy); free(e->weights); free(perm);
+  e->points = pts; e->rows = rows; e->masks = masks; e->fixed_xy = fx; e->weights = wt;
+}
+
+/* ------------------------------------------------------------------ schedules (host scalars) */
+float linear_alpha(long iter, long length, float alpha)      /* lvq_pak.c:903-906 */
+{
+  return alpha * (float)(length - iter) / (float)length;
+}
+float inverse_t_alpha(long iter, long length, float alpha)   /* lvq_pak.c:914-921 */
+{
+  float c = (float)length / 100.0f;
+  return alpha * c / (c + (float)iter);
+}
+ALPHA_FUNC *alpha_func_by_name(const char *name, short *id)
+{
+  if (!name || strcasecmp(name, "linear") == 0) { *id = ALPHA_LINEAR; return linear_alpha; }
+  if (strcasecmp(name, "inverse_t") == 0) { *id = ALPHA_INVERSE_T; return inverse_t_alpha; }
+  *id = ALPHA_UNKNOWN;
+  return NULL;
+}
+
+/* ------------------------------------------------------------------ the HIP back end */
+static somhip_engine *g_engine = NULL;
+
+static somhip_engine *engine(void)
+{
+  if (!g_engine && somhip_engine_create(0, &g_engine)) {
+    fprintf(stderr, "%s\n", somhip_last_error());
+    return NULL;
+  }
+  return g_engine;
+}
+void pak_shutdown(void) { if (g_engine) { somhip_engine_destroy(g_engine); g_engine = NULL; } }
+
+static int32_t *first_labels(struct entries *e)
+{
+  int32_t *l = malloc(sizeof(int32_t) * (e->num_entries + 1));
+  for (long r = 0; r < e->num_entries; r++) l[r] = get_entry_label(&e->rows[r]);
+  return l;
+}
+
+static somhip_codebook *mirror_codes(struct entries *codes, int with_labels)
+{
+  somhip_engine *en = engine();
+  if (!en) return NULL;
+  somhip_codebook *cb = NULL;
+  int32_t *lab = with_labels ? first_labels(codes) : NULL;
+  int rc = somhip_codebook_create(en, codes->points, lab, codes->num_entries, codes->dimension, codes->topol,
+                                  codes->neigh, codes->xdim, codes->ydim, 0, codes->num_entries, &cb);
+  free(lab);
+  if (rc) { fprintf(stderr, "%s\n", somhip_last_error()); return NULL; }
+  return cb;
+}
+static somhip_dataset *mirror_data(struct entries *data, int with_labels)
+{
+  somhip_engine *en = engine();
+  if (!en) return NULL;
+  somhip_dataset *ds = NULL;
+  int32_t *lab = with_labels ? first_labels(data) : NULL;
+  int rc = somhip_dataset_create(en, data->points, data->num_entries, data->dimension,
+                                 (const uint8_t *)data->masks, lab, data->weights, data->fixed_xy, &ds);
+  free(lab);
+  if (rc) { fprintf(stderr, "%s\n", somhip_last_error()); return NULL; }
+  return ds;
+}
+
+/* per-sample WINNER_FUNCTION of the "hip" row: one sample through the same kernels.  Tools
+ * should prefer the epoch-level functions; this keeps per-sample callers working. */
+static int hip_find_winner(struct entries *codes, struct data_entry *sample, struct winner_info *w, int knn)
+{
+  somhip_codebook *cb = codes->userdata ? codes->userdata : (codes->userdata = mirror_codes(codes, 0));
+  if (!cb) return 0;
+  somhip_dataset *ds = NULL;
+  int32_t idx[8], ret = 0;
+  float diff[8];
+  if (knn < 1 || knn > 8) return 0;
+  if (somhip_dataset_create(engine(), sample->points, 1, codes->dimension, (const uint8_t *)sample->mask,
+                            NULL, NULL, NULL, &ds)) return 0;
+  int rc = somhip_find_winners(cb, ds, 0, 1, knn, knn > 1 ? SOMHIP_TIE_KNN : SOMHIP_TIE_FIRST, idx, diff, &ret);
+  somhip_dataset_destroy(ds);
+  if (rc) { fprintf(stderr, "%s\n", somhip_last_error()); return 0; }
+  for (int k = 0; k < knn; k++) {
+    w[k].index = idx[k];
+    w[k].winner = idx[k] >= 0 ? &codes->rows[idx[k]] : NULL;
+    w[k].diff = diff[k];
+  }
+  return ret;
+}
+
+/* the registry (datafile.c:1207-1243).  There is one row, "hip"; the reference's name
+ * "default" is accepted as an alias so existing command lines run unchanged.  Unknown names
+ * warn and fall back exactly as the reference does. */
+static struct vec_functions { const char *name; DIST_FUNCTION *dist; VECTOR_ADAPT *vector_adapt; WINNER_FUNCTION *winner; }
+vec_funcs[] = { {"hip", NULL, NULL, hip_find_winner}, {"default", NULL, NULL, hip_find_winner}, {NULL, NULL, NULL, NULL} };
+
+int set_teach_params(struct teach_params *p, struct entries *codes, struct entries *data, const char *funcname)
+{
+  struct vec_functions *v = vec_funcs;
+  if (funcname)
+    for (; v->name; v++) if (strcasecmp(v->name, funcname) == 0) break;
+  if (funcname && !v->name) {
+    fprintf(stderr, "functions for '%s' not found, using defaults\n", funcname);
+    v = vec_funcs;
+  }
+  p->topol = codes->topol; p->neigh = codes->neigh;
+  p->mapdist = NULL; p->neigh_adapt = NULL;
+  p->dist = v->dist; p->vector_adapt = v->vector_adapt; p->winner = v->winner;
+  p->codes = codes;
+  if (data) p->data = data;
+  p->snapshot = NULL;
+  p->batch = 1;
+  return 0;
+}
+int set_som_params(struct teach_params *p)                   /* som_rout.c:936-947 */
+{
+  if (p->topol != TOPOL_HEXA && p->topol != TOPOL_RECT) return 1;
+  if (p->neigh != NEIGH_BUBBLE && p->neigh != NEIGH_GAUSSIAN) return 1;
+  return 0;
+}
+
+static int save_snapshot(struct teach_params *teach, long iter)   /* lvq_pak.c:665-774, synchronous form */
+{
+  char filename[1024], comment[128];
+  snprintf(filename, sizeof filename, teach->snapshot->filename, iter);
+  snprintf(comment, sizeof comment, "#SNAPSHOT FILE\n#iterations: %ld/%ld\n", iter, teach->length);
+  teach->snapshot->counter++;
+  return save_entries_wcomments(teach->codes, filename, comment);
+}
+
+/* iterations are run in segments that end where the reference would save a snapshot
+ * (after iteration le, when le % interval == 0 && le > 0: som_rout.c:650, lvq_rout.c:559) */
+static long segment_end(struct teach_params *t, long start)
+{
+  if (!t->snapshot || t->snapshot->interval <= 0) return t->length;
+  long next = (start / t->snapshot->interval + 1) * t->snapshot->interval;   /* next le with le % iv == 0, le > start-1 */
+  if (start == 0) next = t->snapshot->interval;
+  long end = next + 1;
+  return end < t->length ? end : t->length;
+}
+
+struct entries *som_training(struct teach_params *teach)     /* som_rout.c:556-671 */
+{
+  struct entries *codes = teach->codes, *data = teach->data;
+  if (set_som_params(teach)) { fprintf(stderr, "som_training: can't set SOM parameters\n"); return NULL; }
+  if (!data || data->num_entries <= 0) { fprintf(stderr, "som_training: can't get data\n"); return NULL; }
+  if (data->dimension != codes->dimension) {
+    fprintf(stderr, "code dimension (%d) != data dimension (%d)\n", codes->dimension, data->dimension);
+    return NULL;
+  }
+  somhip_codebook *cb = mirror_codes(codes, 0);
+  somhip_dataset *ds = mirror_data(data, 0);
+  struct entries *ret = NULL;
+  if (!cb || !ds) goto done;
+  for (long start = 0; start < teach->length;) {
+    long end = segment_end(teach, start);
+    somhip_som_params sp = { teach->length, teach->alpha, teach->radius, teach->alpha_type,
+                             use_fixed_level, use_weights_level, teach->batch > 1 ? teach->batch : 1,
+                             start, end - start, start % data->num_entries };
+    if (somhip_som_train(cb, ds, &sp, NULL, NULL)) { fprintf(stderr, "som_training: %s\n", somhip_last_error()); goto done; }
+    if (teach->snapshot && end - 1 > 0 && (end - 1) % teach->snapshot->interval == 0 && end <= teach->length) {
+      if (somhip_codebook_download(cb, codes->points)) goto done;
+      ifverbose(2) fprintf(stderr, "Saving snapshot, %ld iterations\n", end - 1);
+      if (save_snapshot(teach, end - 1)) fprintf(stderr, "snapshot failed, continuing teaching\n");
+    }
+    start = end;
+  }
+  if (somhip_codebook_download(cb, codes->points)) { fprintf(stderr, "som_training: %s\n", somhip_last_error()); goto done; }
+  ret = codes;
+done:
+  if (cb) somhip_codebook_destroy(cb);
+  if (ds) somhip_dataset_destroy(ds);
+  return ret;
+}
+
+static struct entries *lvq_training(struct teach_params *teach, int kind, float winlen, float epsilon,
+                                    float *talpha, const char *who)
+{
+  struct entries *codes = teach->codes, *data = teach->data;
+  if (!data || data->num_entries <= 0) { fprintf(stderr, "%s: can't get data\n", who); return NULL; }
+  somhip_codebook *cb = mirror_codes(codes, 1);
+  somhip_dataset *ds = mirror_data(data, 1);
+  struct entries *ret = NULL;
+  if (!cb || !ds) goto done;
+  for (long start = 0; start < teach->length;) {
+    long end = segment_end(teach, start);
+    somhip_lvq_params lp = { kind, teach->length, teach->alpha, teach->alpha_type, winlen, epsilon,
+                             start, end - start, start % data->num_entries };
+    if (somhip_lvq_train(cb, ds, &lp, talpha, NULL, NULL)) { fprintf(stderr, "%s: %s\n", who, somhip_last_error()); goto done; }
+    if (teach->snapshot && end - 1 > 0 && (end - 1) % teach->snapshot->interval == 0 && end <= teach->length) {
+      if (somhip_codebook_download(cb, codes->points)) goto done;
+      if (save_snapshot(teach, end - 1)) fprintf(stderr, "snapshot failed\n");
+    }
+    start = end;
+  }
+  if (somhip_codebook_download(cb, codes->points)) goto done;
+  ret = codes;
+done:
+  if (cb) somhip_codebook_destroy(cb);
+  if (ds) somhip_dataset_destroy(ds);
+  return ret;
+}
+struct entries *lvq1_training(struct teach_params *t) { return lvq_training(t, SOMHIP_LVQ1, 0, 0, NULL, "lvq1_training"); }
+struct entries *lvq2_training(struct teach_params *t, float winlen) { return lvq_training(t, SOMHIP_LVQ2, winlen, 0, NULL, "lvq2_training"); }
+struct entries *lvq3_training(struct teach_params *t, float eps, float winlen) { return lvq_training(t, SOMHIP_LVQ3, winlen, eps, NULL, "lvq3_training"); }
+
+struct entries *olvq1_training(struct teach_params *teach, const char *infile, const char *outfile)  /* lvq_rout.c:584-697 */
+{
+  long noc = teach->codes->num_entries;
+  float *talpha = malloc(sizeof(float) * (noc + 1));
+  float alpha = teach->alpha;
+  if (alpha == 0.0f) {                                        /* :615-622 */
+    if (!alpha_read(talpha, noc, infile)) {
+      alpha = 0.3f;
+      for (long i = 0; i < noc; i++) talpha[i] = alpha;
+    }
+  } else {
+    for (long i = 0; i < noc; i++) talpha[i] = alpha;
+  }
+  float keep = teach->alpha;
+  teach->alpha = alpha;                                       /* the clamp of :671 is the local `alpha` */
+  struct entries *r = lvq_training(teach, SOMHIP_OLVQ1, 0, 0, talpha, "olvq1_training");
+  teach->alpha = keep;
+  if (r) alpha_write(talpha, noc, outfile);                  /* :694 */
+  free(talpha);
+  return r;
+}
+
+int find_all_winners(struct teach_params *teach, int32_t *index, float *diff, int32_t *ret)
+{
+  somhip_codebook *cb = mirror_codes(teach->codes, 0);
+  somhip_dataset *ds = mirror_data(teach->data, 0);
+  int rc = 1;
+  if (cb && ds) {
+    rc = somhip_find_winners(cb, ds, 0, teach->data->num_entries, 1, SOMHIP_TIE_FIRST, index, diff, ret);
+    if (rc) fprintf(stderr, "%s\n", somhip_last_error());
+  }
+  if (cb) somhip_codebook_destroy(cb);
+  if (ds) somhip_dataset_destroy(ds);
+  return rc;
+}
+
+float find_qerror(struct teach_params *teach)                 /* som_rout.c:678-731 */
+{
+  if (set_som_params(teach)) { fprintf(stderr, "find_qerror: can't set SOM parameters\n"); return -1; }
+  long n = teach->data->num_entries;
+  if (n <= 0) { fprintf(stderr, "find_qerror: can't get data\n"); return -1.0f; }
+  int32_t *idx = malloc(sizeof(int32_t) * n), *ret = malloc(sizeof(int32_t) * n);
+  float *diff = malloc(sizeof(float) * n);
+  float qerror = 0.0f;
+  if (find_all_winners(teach, idx, diff, ret)) qerror = -1.0f;
+  else
+    for (long i = 0; i < n; i++) {
+      if (ret[i] == 0) continue;                              /* ignore empty vectors, :712 */
+      qerror += sqrt((double)diff[i]);                        /* float accumulator, :715 */
+    }
+  free(idx); free(ret); free(diff);
+  return qerror;
+}

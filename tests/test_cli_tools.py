@@ -1,0 +1,159 @@
+"""The C command-line tools (som_lvq_pak_amd/host): same flags, files and output text as the
+reference's vsom / lvq1..olvq1 / qerror / accuracy / vcal.  GPU tests replay the CLI chains
+whose outputs the REAL reference produced (tests/golden/cli) and compare bytes."""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+BIN = os.path.join(ROOT, "som_lvq_pak_amd", "host", "bin")
+DATA = os.path.join(GOLDEN, "data")
+CLI = os.path.join(GOLDEN, "cli")
+EXPECTED = json.load(open(os.path.join(CLI, "expected.json")))
+
+
+@pytest.fixture(scope="module")
+def tools():
+    if not os.path.exists(os.path.join(BIN, "vsom")):
+        subprocess.check_call(["make", "-s", "-C", ROOT, "lib"])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "som_lvq_pak_amd", "host")])
+    return BIN
+
+
+def run(tool, *args, cwd=None, check=True):
+    p = subprocess.run([os.path.join(BIN, tool)] + [str(a) for a in args], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, cwd=cwd)
+    if check:
+        assert p.returncode == 0, (tool, args, p.stderr)
+    return p
+
+
+def md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+# ------------------------------------------------------------------ CPU side
+def test_tools_build_and_usage(tools):
+    for t in ("vsom", "lvqtrain", "qerror", "accuracy", "vcal", "lvq1", "olvq1", "lvq2", "lvq3"):
+        p = run(t, "-help")
+        assert "MI355X" in p.stdout
+    p = run("qerror", "-din", "x", check=False)          # required flag missing: message + exit(-1)
+    assert p.returncode == 255 and "Can't find asked option -cin" in p.stderr
+    p = run("lvqtrain", "-type", "nosuch", "-din", "a", "-cin", "b", "-cout", "c", "-rlen", 1, check=False)
+    assert p.returncode == 1 and "Unknown LVQ type nosuch" in p.stderr
+
+
+def test_tools_refuse_without_gpu(tools, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = run("vsom", "-din", os.path.join(DATA, "ex.dat"), "-cin", os.path.join(CLI, "som_init_hexa_bubble.cod"),
+            "-cout", tmp_path / "o.cod", "-rlen", 10, "-alpha", 0.05, "-radius", 3, "-v", 0, check=False)
+    assert p.returncode == 1 and "no CPU path" in p.stderr
+    assert not os.path.exists(tmp_path / "o.cod")
+    p = run("vsom", "-din", os.path.join(DATA, "ex1.dat"), "-cin", os.path.join(CLI, "som_init_hexa_bubble.cod"),
+            "-cout", tmp_path / "o.cod", "-rlen", 10, "-alpha", 0.05, "-radius", 3, check=False)
+    assert p.returncode == 1 and "different dimensions" in p.stderr
+
+
+# ------------------------------------------------------------------ GPU side
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["hexa_bubble", "hexa_gaussian", "rect_bubble", "rect_gaussian"])
+def test_vsom_and_qerror_match_reference_cli(tools, tmp_path, tag):
+    ex = EXPECTED["som"][tag]
+    out = tmp_path / "out.cod"
+    run("vsom", "-din", os.path.join(DATA, "ex.dat"), "-cin", os.path.join(CLI, ex["init"]), "-cout", out,
+        "-rlen", ex["rlen"], "-alpha", ex["alpha"], "-radius", ex["radius"], "-v", 0)
+    assert md5(out) == ex["md5"]
+    p = run("qerror", "-din", os.path.join(DATA, "ex.dat"), "-cin", out, "-v", 0)
+    assert p.stdout == ex["qerror_stdout"]
+
+
+@pytest.mark.gpu
+def test_vsom_variants(tools, tmp_path):
+    d, init = os.path.join(DATA, "ex.dat"), os.path.join(CLI, "som_init_hexa_bubble.cod")
+    out = tmp_path / "o.cod"
+    run("vsom", "-din", d, "-cin", init, "-cout", out, "-rlen", 5000, "-alpha", 0.05, "-radius", 10,
+        "-alpha_type", "inverse_t", "-selfuncs", "hip", "-v", 0)
+    assert md5(out) == EXPECTED["som"]["inverse_t"]["md5"]
+    run("vsom", "-din", d, "-cin", init, "-cout", out, "-rlen", 5000, "-alpha", 0.05, "-radius", 10,
+        "-rand", 7, "-v", 0)
+    assert md5(out) == EXPECTED["som"]["rand7"]["md5"]
+    p = run("vsom", "-din", d, "-cin", init, "-cout", out, "-rlen", 100, "-alpha", 0.05, "-radius", 10,
+            "-selfuncs", "nosuch", "-v", 0)
+    assert "functions for 'nosuch' not found, using defaults" in p.stderr
+
+
+@pytest.mark.gpu
+def test_somexample_chain(tools, tmp_path):
+    """reference Makefile:195-205 -> qerror 3.571006, then vcal"""
+    d = os.path.join(DATA, "ex.dat")
+    cod = tmp_path / "ex.cod"
+    shutil.copyfile(os.path.join(CLI, "som_init_hexa_bubble.cod"), cod)
+    run("vsom", "-din", d, "-cin", cod, "-cout", cod, "-rlen", 1000, "-alpha", 0.05, "-radius", 10, "-v", 0)
+    run("vsom", "-din", d, "-cin", cod, "-cout", cod, "-rlen", 10000, "-alpha", 0.02, "-radius", 3, "-v", 0)
+    assert md5(cod) == EXPECTED["som"]["somexample"]["md5"]
+    p = run("qerror", "-din", d, "-cin", cod, "-v", 0)
+    assert p.stdout == "3.571006\n"
+    p = run("qerror", "-din", d, "-cin", cod)
+    assert p.stdout.endswith("is 3.571006 per sample (3840 samples)\n")
+    lab = tmp_path / "lab.cod"
+    run("vcal", "-din", os.path.join(DATA, "ex_fts.dat"), "-cin", cod, "-cout", lab, "-v", 0)
+    assert md5(lab) == EXPECTED["som"]["somexample_vcal_md5"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["lvq1_10000", "lvq1", "lvq2", "lvq3", "olvq1", "olvq1_default"])
+def test_lvq_tools_match_reference_cli(tools, tmp_path, tag):
+    ex = EXPECTED["lvq"][tag]
+    out = tmp_path / "out.cod"
+    run(ex["tool"], "-din", os.path.join(DATA, "ex1.dat"), "-cin", os.path.join(CLI, "lvq_init.cod"),
+        "-cout", out, *ex["args"], "-v", 0)
+    assert md5(out) == ex["md5"]
+    assert not os.path.exists(tmp_path / "out.lra")            # lvqtrain.c:249 removes it
+    p = run("accuracy", "-din", os.path.join(DATA, "ex2.dat"), "-cin", out, "-v", 0)
+    assert p.stdout == ex["accuracy_stdout"]
+    # the same through `lvqtrain -type`
+    out2 = tmp_path / "out2.cod"
+    run("lvqtrain", "-type", ex["tool"], "-din", os.path.join(DATA, "ex1.dat"),
+        "-cin", os.path.join(CLI, "lvq_init.cod"), "-cout", out2, *ex["args"], "-v", 0)
+    assert md5(out2) == ex["md5"]
+
+
+@pytest.mark.gpu
+def test_snapshots_and_cfout(tools, tmp_path):
+    d, init = os.path.join(DATA, "ex.dat"), os.path.join(CLI, "som_init_hexa_bubble.cod")
+    out = tmp_path / "o.cod"
+    run("vsom", "-din", d, "-cin", init, "-cout", out, "-rlen", 5000, "-alpha", 0.05, "-radius", 10,
+        "-snapinterval", 2000, "-snapfile", str(tmp_path / "snap_%ld.cod"), "-v", 0)
+    assert md5(out) == EXPECTED["som"]["hexa_bubble"]["md5"]     # segments change nothing
+    for it in (2000, 4000):
+        txt = open(tmp_path / ("snap_%d.cod" % it)).read().splitlines()
+        assert txt[0] == "5 hexa 12 8 bubble" and txt[1] == "#SNAPSHOT FILE" and txt[2] == "#iterations: %d/5000" % it
+        assert len(txt) == 3 + 96
+    cf = tmp_path / "cf.txt"
+    run("accuracy", "-din", os.path.join(DATA, "ex2.dat"), "-cin", os.path.join(CLI, "lvq_lvq1.cod"),
+        "-cfout", cf, "-v", 0)
+    flags = open(cf).read().split()
+    assert len(flags) == 1962 and 100.0 * flags.count("1") / 1962 == pytest.approx(87.56, abs=0.005)
+
+
+@pytest.mark.gpu
+def test_vsom_minibatch_flag(tools, tmp_path, oracle, exdata):
+    """-batch B runs the mini-batch schedule: equals the batch oracle, bytes of the .cod included"""
+    from conftest import read_cod
+    from som_lvq_pak_amd import textio
+    ini = read_cod("som_init_hexa_bubble.cod")
+    want, _, _ = oracle.som_train(ini.points, 12, 8, 3, 1, exdata["ex"].points, 5000, 0.05, 10.0, batch=64, trace=False)
+    ini.points = want
+    ref = tmp_path / "want.cod"
+    textio.write_entries(str(ref), ini)
+    out = tmp_path / "o.cod"
+    run("vsom", "-din", os.path.join(DATA, "ex.dat"), "-cin", os.path.join(CLI, "som_init_hexa_bubble.cod"),
+        "-cout", out, "-rlen", 5000, "-alpha", 0.05, "-radius", 10, "-batch", 64, "-v", 0)
+    assert md5(out) == md5(ref)
