@@ -254,6 +254,9 @@ def main():
                              "rows_per_sample": (stats_after["rows"] - stats_before["rows"])
                              / max(stats_after["samples"] - stats_before["samples"], 1),
                              "max_groups_per_sample": stats_after["max_groups_per_sample"]},
+            "update_stats": {"row_updates": stats_after["row_updates"] - stats_before["row_updates"],
+                             "lane_efficiency": (stats_after["row_updates"] - stats_before["row_updates"])
+                             / max(64 * (stats_after["group_updates"] - stats_before["group_updates"]), 1)},
             "kernels_ms": {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in table.items() if v[0]},
         }
         print(json.dumps(out))

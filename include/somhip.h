@@ -58,8 +58,9 @@ enum { SOMHIP_SCAN_DIRECT = 0, SOMHIP_SCAN_MFMA = 1 };
 int  somhip_engine_set_scan_mode(somhip_engine *e, int mode);
 /* cumulative re-rank statistics of the MFMA path since engine creation:
  * out[0] = row groups re-ranked, out[1] = rows re-ranked, out[2] = max groups for one sample,
- * out[3] = samples searched, out[4] = (row, iteration) updates applied by mini-batch runs */
-int  somhip_scan_stats(somhip_engine *e, uint64_t out[5]);
+ * out[3] = samples searched, out[4] = (row, iteration) updates applied by mini-batch runs,
+ * out[5] = (row group, iteration) pairs with at least one update */
+int  somhip_scan_stats(somhip_engine *e, uint64_t out[6]);
 
 /* ---- codebook mirror -------------------------------------------------------
  * rows: host, row-major [n_rows][dim] fp32, row k = list position k of the

@@ -593,24 +593,101 @@ __global__ void k_decode_winners(const uint64_t *__restrict__ keys, const StepSc
 }
 
 // =====================================================================================
-// K4: in-order neighbourhood update of a run of `count` samples whose winners are known.
+// K4b: who updates whom.  For every row group (64 code rows) the samples of the run whose
+// neighbourhood reaches it, in iteration order, each with the 64-bit mask of the member
+// rows: hexa_dist/rect_dist <= radius (som_rout.c:496) decided per (row, sample) with the
+// exact lattice arithmetic, after a cheap reach test on lattice rows.  One workgroup per
+// row group, one thread per sample (256 at a time), ordered compaction by ballot/prefix.
+// Gaussian neighbourhoods touch every row, so their list is every taught sample.
+//   cnt[g]                 number of entries
+//   ent[g*count + k]       {sample index in the run, member mask}
+// =====================================================================================
+struct MemberEntry { uint32_t sample; uint32_t pad; unsigned long long mask; };
+
+template <bool GAUSS>
+__global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
+                                                     const int2 *__restrict__ bxy,
+                                                     const StepScalars *__restrict__ sc,
+                                                     uint32_t *__restrict__ cnt,
+                                                     MemberEntry *__restrict__ ent,
+                                                     unsigned long long *__restrict__ stats) {
+  __shared__ uint32_t s_wcount[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t g = blockIdx.x;
+  const uint32_t xdim = static_cast<uint32_t>(cb.xdim);
+  const int64_t r0 = g * WAVE;
+  const int64_t r_last = (r0 + WAVE < cb.n ? r0 + WAVE : cb.n) - 1;
+  const int nlive = static_cast<int>(r_last - r0 + 1);
+  const uint32_t gr0 = static_cast<uint32_t>(r0 + cb.row_offset);
+  const int g_ty0 = static_cast<int>(gr0 / xdim);
+  const int g_ty1 = static_cast<int>(static_cast<uint32_t>(r_last + cb.row_offset) / xdim);
+  const int g_tx0 = static_cast<int>(gr0 % xdim);
+  const bool small_map = cb.xdim <= 1024 && g_ty1 < 1024;
+  const unsigned long long live_mask = nlive >= 64 ? ~0ull : ((1ull << nlive) - 1);
+  MemberEntry *out = ent + g * count;
+  uint32_t base = 0;
+  unsigned long long rows_total = 0, pairs_total = 0;
+
+  for (int64_t b0 = 0; b0 < count; b0 += 256) {
+    const int64_t b = b0 + tid;
+    unsigned long long m = 0;
+    if (b < count) {
+      const int2 w = bxy[b];
+      const StepScalars s = sc[b];
+      if (w.x >= 0 && w.y + s.reach >= g_ty0 && w.y - s.reach <= g_ty1) {
+        if (GAUSS) m = live_mask;
+        else {
+          int tx = g_tx0, ty = g_ty0;
+          for (int u = 0; u < nlive; u++) {
+            const float lsq = small_map ? lattice_sq_small(cb.topol, w.x, w.y, tx, ty)
+                                        : lattice_sq(cb.topol, w.x, w.y, tx, ty);
+            if (lsq <= s.thresh) m |= 1ull << u;
+            if (++tx == static_cast<int>(xdim)) { tx = 0; ty++; }
+          }
+        }
+      }
+    }
+    const bool on = m != 0;
+    const unsigned long long bal = __ballot(on);
+    if (lane == 0) s_wcount[wave] = __popcll(bal);
+    __syncthreads();
+    uint32_t off = base;
+    for (int w2 = 0; w2 < wave; w2++) off += s_wcount[w2];
+    if (on) {
+      MemberEntry e;
+      e.sample = static_cast<uint32_t>(b); e.pad = 0; e.mask = m;
+      out[off + __popcll(bal & ((1ull << lane) - 1))] = e;
+      rows_total += __popcll(m);
+      pairs_total += 1;
+    }
+    base += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+    __syncthreads();
+  }
+  if (tid == 0) cnt[g] = base;
+  // instrumentation: (row, iteration) updates and (row group, iteration) pairs of this run
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    rows_total += __shfl_xor(rows_total, off, WAVE);
+    pairs_total += __shfl_xor(pairs_total, off, WAVE);
+  }
+  if (lane == 0 && stats) {
+    if (rows_total) atomicAdd(stats + 3, rows_total);
+    if (pairs_total) atomicAdd(stats + 4, pairs_total);
+  }
+}
+
+// =====================================================================================
+// K4: in-order neighbourhood update of a run of samples, driven by K4b's member lists.
 //
 // bubble_adapt (som_rout.c:472-506) / gaussian_adapt (:511-549) + adapt_vector
 // (lvq_pak.c:339-351) for iterations batch_start .. batch_start+count-1, applied to
 // every code row in iteration order.  One lane = one code row, QW chunks (4*QW dims) of
 // it held in registers across the whole run, so each touched row is read and written
-// once per run whatever the batch size.
-//
-// A workgroup = ONE row group (64 rows) x 4 consecutive dim slices (one per wave): the
-// four waves see the same membership pattern, so they stay balanced between barriers.
-// Samples are processed in tiles of TB:
-//   1. per-sample scalars -> LDS; samples whose neighbourhood cannot reach the group's
-//      lattice rows are dropped on the host-computed reach (whole tile skipped if none);
-//   2. each wave decides membership of a quarter of the tile's samples once for the whole
-//      workgroup: 64-bit lane mask per sample (bubble) or per-lane alpha (gaussian);
-//   3. the slices of the samples that touch the group are staged into LDS (coalesced);
-//   4. every wave walks the tile in iteration order: one LDS word tells it whether and
-//      which lanes update, x comes back as broadcast reads.
+// once per run whatever the batch size.  A workgroup = ONE row group x 4 consecutive dim
+// slices (one per wave): the four waves see the same member list, so they stay balanced
+// between barriers.  The list is walked in tiles of TB entries: entry scalars -> LDS, the
+// tile's sample slices staged into LDS (one coalesced pass), then every wave applies the
+// tile's updates in order (member lanes from the entry's mask, x as broadcast reads).
 // =====================================================================================
 template <int QW, int TB, bool GAUSS, bool MASKED>
 __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *__restrict__ rows,
@@ -619,140 +696,94 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
                                                         int64_t count,
                                                         const int2 *__restrict__ bxy,
                                                         const StepScalars *__restrict__ sc,
-                                                        unsigned long long *__restrict__ member_count) {
+                                                        const uint32_t *__restrict__ cnt,
+                                                        const MemberEntry *__restrict__ ent) {
   constexpr int BQ = 4 * QW;                          // chunks per workgroup
-  constexpr int ST = 256;                             // samples per super-tile (one per thread)
   __shared__ float4 xs[TB][BQ];
   __shared__ uint32_t ms[MASKED ? TB : 1][MASKED ? BQ : 1];   // 4 mask bits per chunk
   __shared__ float s_ga[GAUSS ? TB : 1][GAUSS ? WAVE : 1];    // gaussian: per-lane alpha
   __shared__ unsigned long long s_mask[TB];
-  __shared__ unsigned long long s_hitbits[ST / WAVE];
-  __shared__ long long s_xoff[ST];                    // element offset of the sample's row
-  __shared__ int s_bx[ST], s_by[ST];
-  __shared__ float s_alpha[ST], s_thr[ST];
-  __shared__ int s_list[TB], s_nlist;
+  __shared__ long long s_xoff[TB];
+  __shared__ float s_alpha[TB], s_thr[TB];
+  __shared__ int s_bx[TB], s_by[TB];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t g = blockIdx.x;
+  const uint32_t n_ent = cnt[g];
+  if (n_ent == 0) return;                             // nothing in this run touches the group
   const int qblk = blockIdx.y * BQ;
   const int q0 = qblk + wave * QW;
-  const uint32_t xdim = static_cast<uint32_t>(cb.xdim);
-  const int64_t row = g * WAVE + lane;
-  const bool live = row < cb.n;
-  const uint32_t grow = static_cast<uint32_t>(row + cb.row_offset);
-  const int tx = static_cast<int>(grow % xdim), ty = static_cast<int>(grow / xdim);
-  const int64_t r_last = (g * WAVE + WAVE < cb.n ? g * WAVE + WAVE : cb.n) - 1;
-  const int g_ty0 = static_cast<int>(static_cast<uint32_t>(g * WAVE + cb.row_offset) / xdim);
-  const int g_ty1 = static_cast<int>(static_cast<uint32_t>(r_last + cb.row_offset) / xdim);
-  const bool small_map = cb.xdim <= 1024 && g_ty1 < 1024;
   const bool vec = (cb.d & 3) == 0;
+  const MemberEntry *list = ent + g * count;
+  const uint32_t xdim = static_cast<uint32_t>(cb.xdim);
+  const uint32_t grow = static_cast<uint32_t>(g * WAVE + lane + cb.row_offset);
+  const int tx = static_cast<int>(grow % xdim), ty = static_cast<int>(grow / xdim);
 
   float4 c[QW];
 #pragma unroll
   for (int j = 0; j < QW; j++)
     c[j] = (q0 + j < cb.d4) ? *tile_ptr(cb, g, q0 + j, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
-  bool dirty = false;
-  unsigned long long members = 0;
 
-  for (int64_t T0 = 0; T0 < count; T0 += ST) {
-    // ---- 1. scalars of 256 samples (one global round trip) + reach test
-    {
-      int bx = -1, by = -1, hit = 0;
-      float al = 0.f, th = 0.f;
-      const int64_t b = T0 + tid;
-      if (b < count) {
-        const int2 w = bxy[b];
-        const StepScalars s = sc[b];
-        bx = w.x; by = w.y; al = s.alpha; th = s.thresh;
-        hit = (bx >= 0) && (by + s.reach >= g_ty0) && (by - s.reach <= g_ty1);
-        if (hit) s_xoff[tid] = ((data_first + b) % n_rows) * cb.d;
-      }
-      s_bx[tid] = bx; s_by[tid] = by; s_alpha[tid] = al; s_thr[tid] = th;
-      const unsigned long long hb = __ballot(hit);
-      if (lane == 0) s_hitbits[wave] = hb;
+  for (uint32_t k0 = 0; k0 < n_ent; k0 += TB) {
+    const int tb = static_cast<int>(n_ent - k0 < TB ? n_ent - k0 : TB);
+    // ---- entry scalars
+    if (tid < tb) {
+      const MemberEntry e = list[k0 + tid];
+      const StepScalars s = sc[e.sample];
+      s_mask[tid] = e.mask;
+      s_alpha[tid] = s.alpha;
+      s_xoff[tid] = ((data_first + e.sample) % n_rows) * cb.d;
+      if (GAUSS) { const int2 w = bxy[e.sample]; s_bx[tid] = w.x; s_by[tid] = w.y; s_thr[tid] = s.thresh; }
     }
     __syncthreads();
-    for (int t0 = 0; t0 < ST && T0 + t0 < count; t0 += TB) {
-      // hit bits of this sub-tile (TB divides 64)
-      const unsigned long long hbits = (s_hitbits[t0 >> 6] >> (t0 & 63)) & ((TB == 64) ? ~0ull : ((1ull << TB) - 1));
-      if (hbits == 0) continue;                          // uniform
-      // ---- 2. membership, once per (row group, sample)
-      for (int s = wave; s < TB; s += 4) {
-        unsigned long long m = 0;
-        if ((hbits >> s) & 1ull) {
-          const int ss = t0 + s;
-          const float lsq = small_map ? lattice_sq_small(cb.topol, s_bx[ss], s_by[ss], tx, ty)
-                                      : lattice_sq(cb.topol, s_bx[ss], s_by[ss], tx, ty);
-          bool member;
-          if (GAUSS) { s_ga[s][lane] = gaussian_alpha(lsq, s_thr[ss], s_alpha[ss]); member = live; }
-          else member = live && (lsq <= s_thr[ss]);
-          m = __ballot(member);
-        }
-        if (lane == 0) s_mask[s] = m;
-        if (blockIdx.y == 0) members += __popcll(m);
-      }
-      __syncthreads();
-      // compact list of the samples that touch this group, in iteration order
-      if (wave == 0) {
-        const bool on = lane < TB && s_mask[lane < TB ? lane : 0] != 0;
-        const unsigned long long bal = __ballot(on);
-        if (on) s_list[__popcll(bal & ((1ull << lane) - 1))] = lane;
-        if (lane == 0) s_nlist = __popcll(bal);
-      }
-      __syncthreads();
-      const int nlist = s_nlist;
-      if (nlist == 0) continue;                          // uniform
-      // ---- 3. slices of those samples -> LDS
-      for (int e = tid; e < nlist * BQ; e += 256) {
-        const int i = e / BQ, j = e % BQ, q = qblk + j;
-        if (q < cb.d4) {
-          const long long xo = s_xoff[t0 + s_list[i]];
-          const float *xr = rows + xo;
-          xs[i][j] = vec ? reinterpret_cast<const float4 *>(xr)[q] : load_x4<false>(xr, q, cb.d);
-          if (MASKED) {
-            const uint8_t *mk = mask + xo;
-            uint32_t mm = 0;
+    // ---- sample slices -> LDS (+ gaussian: per-lane alpha, once per workgroup)
+    for (int e = tid; e < tb * BQ; e += 256) {
+      const int i = e / BQ, j = e % BQ, q = qblk + j;
+      if (q < cb.d4) {
+        const long long xo = s_xoff[i];
+        const float *xr = rows + xo;
+        xs[i][j] = vec ? reinterpret_cast<const float4 *>(xr)[q] : load_x4<false>(xr, q, cb.d);
+        if (MASKED) {
+          const uint8_t *mk = mask + xo;
+          uint32_t mm = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-              if (q * 4 + u >= cb.d || mk[q * 4 + u] != 0) mm |= 1u << u;
-            ms[i][j] = mm;
-          }
+          for (int u = 0; u < 4; u++)
+            if (q * 4 + u >= cb.d || mk[q * 4 + u] != 0) mm |= 1u << u;
+          ms[i][j] = mm;
         }
       }
-      __syncthreads();
-      // ---- 4. the updates, in iteration order
-      if (q0 < cb.d4) {
-        for (int i = 0; i < nlist; i++) {
-          const int s = s_list[i];
-          if ((s_mask[s] >> lane) & 1ull) {
-            const float a = GAUSS ? s_ga[s][lane] : s_alpha[t0 + s];
-            dirty = true;
+    }
+    if (GAUSS) {
+      for (int i = wave; i < tb; i += 4)
+        s_ga[i][lane] = gaussian_alpha(lattice_sq(cb.topol, s_bx[i], s_by[i], tx, ty), s_thr[i], s_alpha[i]);
+    }
+    __syncthreads();
+    // ---- the tile's updates, in iteration order
+    if (q0 < cb.d4) {
+      for (int i = 0; i < tb; i++) {
+        if ((s_mask[i] >> lane) & 1ull) {
+          const float a = GAUSS ? s_ga[i][lane] : s_alpha[i];
 #pragma unroll
-            for (int j = 0; j < QW; j++) {
-              const float4 n = adapt4(c[j], xs[i][wave * QW + j], a);
-              if (MASKED) {
-                const uint32_t mm = ms[i][wave * QW + j];
-                if (!(mm & 1u)) c[j].x = n.x;
-                if (!(mm & 2u)) c[j].y = n.y;
-                if (!(mm & 4u)) c[j].z = n.z;
-                if (!(mm & 8u)) c[j].w = n.w;
-              } else {
-                c[j] = n;      // padding dims: x pad = 0, c pad = 0 -> stays 0
-              }
+          for (int j = 0; j < QW; j++) {
+            const float4 n = adapt4(c[j], xs[i][wave * QW + j], a);
+            if (MASKED) {
+              const uint32_t mm = ms[i][wave * QW + j];
+              if (!(mm & 1u)) c[j].x = n.x;
+              if (!(mm & 2u)) c[j].y = n.y;
+              if (!(mm & 4u)) c[j].z = n.z;
+              if (!(mm & 8u)) c[j].w = n.w;
+            } else {
+              c[j] = n;      // padding dims: x pad = 0, c pad = 0 -> stays 0
             }
           }
         }
       }
-      __syncthreads();
     }
-    __syncthreads();          // s_* of this super-tile are rewritten next trip
+    __syncthreads();
   }
-  if (dirty) {
 #pragma unroll
-    for (int j = 0; j < QW; j++)
-      if (q0 + j < cb.d4) *tile_ptr_w(cb, g, q0 + j, lane) = c[j];
-  }
-  if (blockIdx.y == 0 && member_count && lane == 0 && members) atomicAdd(member_count, members);
+  for (int j = 0; j < QW; j++)
+    if (q0 + j < cb.d4) *tile_ptr_w(cb, g, q0 + j, lane) = c[j];
 }
 
 // =====================================================================================

@@ -60,12 +60,13 @@ enum KernelId {
   KID_DIST_MFMA,
   KID_RERANK,
   KID_NORMS,
+  KID_MEMBERS,
   KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {
     "k_scan_exact", "k_som_update_run", "k_som_online_step", "k_lvq_online_step",
     "k_pack_samples", "k_merge_topk", "k_scan_masked", "k_layout", "k_decode_winners",
-    "k_dist_mfma", "k_rerank", "k_norms_tau"};
+    "k_dist_mfma", "k_rerank", "k_norms_tau", "k_som_members"};
 extern "C" int somhip_kernel_count(void) { return KID_COUNT; }
 extern "C" const char *somhip_kernel_name(int i) { return (i >= 0 && i < KID_COUNT) ? kKernelNames[i] : ""; }
 
@@ -150,8 +151,8 @@ extern "C" int somhip_engine_create(int device, somhip_engine **out) {
   somhip_engine *e = new somhip_engine();
   e->device = device;
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  HIPCHK(hipMalloc((void **)&e->d_stats, 4 * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(e->d_stats, 0, 4 * sizeof(unsigned long long)));
+  HIPCHK(hipMalloc((void **)&e->d_stats, 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(e->d_stats, 0, 8 * sizeof(unsigned long long)));
   *out = e;
   return 0;
 }
@@ -177,11 +178,11 @@ extern "C" int somhip_engine_set_scan_mode(somhip_engine *e, int mode) {
   e->scan_mode = mode;
   return 0;
 }
-extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[5]) {
-  unsigned long long h[4];
+extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[6]) {
+  unsigned long long h[8];
   HIPCHK(hipMemcpyAsync(h, e->d_stats, sizeof h, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = e->samples_searched; out[4] = h[3];
+  out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = e->samples_searched; out[4] = h[3]; out[5] = h[4];
   return 0;
 }
 extern "C" int somhip_timing_enable(somhip_engine *e, int on) { CHK(timing_flush(e)); e->timing = on != 0; return 0; }
@@ -670,19 +671,30 @@ static int som_update_run(somhip_codebook *cb, somhip_dataset *ds, int64_t data_
   somhip_engine *e = cb->e;
   const bool G = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN, M = ds->d_mask != nullptr;
   constexpr int QW = 8, TB = 32;
-  void *dbxy;
+  void *dbxy, *dcnt, *dent;
   CHK(engine_scratch(e, 8, sizeof(int2) * (size_t)count, &dbxy));
+  CHK(engine_scratch(e, 9, sizeof(uint32_t) * (size_t)cb->v.ngroups, &dcnt));
+  CHK(engine_scratch(e, 10, sizeof(MemberEntry) * (size_t)cb->v.ngroups * (size_t)count, &dent));
   {
     LaunchTimer t(e, KID_DECODE);
     hipLaunchKernelGGL(k_decode_winners, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream,
                        d_keys, d_sc, count, cb->v.xdim, (int2 *)dbxy);
   }
   HIPCHK(hipGetLastError());
+  {
+    LaunchTimer t(e, KID_MEMBERS);
+    if (G) hipLaunchKernelGGL(k_som_members<true>, dim3((unsigned)cb->v.ngroups), dim3(256), 0, e->stream, cb->v, count,
+                              (const int2 *)dbxy, d_sc, (uint32_t *)dcnt, (MemberEntry *)dent, e->d_stats);
+    else hipLaunchKernelGGL(k_som_members<false>, dim3((unsigned)cb->v.ngroups), dim3(256), 0, e->stream, cb->v, count,
+                            (const int2 *)dbxy, d_sc, (uint32_t *)dcnt, (MemberEntry *)dent, e->d_stats);
+  }
+  HIPCHK(hipGetLastError());
   dim3 grid((unsigned)cb->v.ngroups, (unsigned)((cb->v.d4 + 4 * QW - 1) / (4 * QW)));
   LaunchTimer t(e, KID_SOM_UPDATE_RUN);
 #define GO(GG, MM)                                                                                   \
   hipLaunchKernelGGL((k_som_update_run<QW, TB, GG, MM>), grid, dim3(256), 0, e->stream, cb->v, ds->d_rows, \
-                     (const uint8_t *)ds->d_mask, ds->n, data_first, count, (const int2 *)dbxy, d_sc, e->d_stats + 3)
+                     (const uint8_t *)ds->d_mask, ds->n, data_first, count, (const int2 *)dbxy, d_sc,   \
+                     (const uint32_t *)dcnt, (const MemberEntry *)dent)
   if (G && M) GO(true, true); else if (G) GO(true, false); else if (M) GO(false, true); else GO(false, false);
 #undef GO
   HIPCHK(hipGetLastError());

@@ -49,10 +49,10 @@ class Engine:
         check(self.lib.somhip_engine_set_scan_mode(self.h, {"direct": 0, "mfma": 1}[mode]))
 
     def scan_stats(self):
-        out = (C.c_uint64 * 5)()
+        out = (C.c_uint64 * 6)()
         check(self.lib.somhip_scan_stats(self.h, out))
         return {"groups": out[0], "rows": out[1], "max_groups_per_sample": out[2], "samples": out[3],
-                "row_updates": out[4]}
+                "row_updates": out[4], "group_updates": out[5]}
 
     # --- timing table (HIP events on the engine's stream) ---
     def timing(self, on=True):
