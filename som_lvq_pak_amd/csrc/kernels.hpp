@@ -365,7 +365,7 @@ __global__ void k_row_norms(CbView cb, float *__restrict__ cn, unsigned int *__r
 // tau[b] for the samples of a run (one wave per sample)
 __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int d, int64_t first,
                              int64_t count, const unsigned int *__restrict__ cn_max_bits,
-                             float *__restrict__ tau) {
+                             double err_coeff, float *__restrict__ tau) {
   const int64_t b = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (b >= count) return;
@@ -375,12 +375,11 @@ __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, WAVE);
   if (lane == 0) {
+    // err_coeff = the host's bound on |s~ + ||x||^2 - d| / (||x|| + ||c||)^2 for the GEMM in use
     const double u = 5.9604644775390625e-08;                         // 2^-24
-    const double k = (d + 2) * u;
-    const double gam = k / (1.0 - k);
     const double cmax = sqrt(static_cast<double>(__uint_as_float(*cn_max_bits)) * (1.0 + 4.0 * d * u));
     const double s = sqrt(acc) + cmax;
-    const double t = 4.0 * gam * s * s * 1.001;
+    const double t = 2.0 * err_coeff * s * s * 1.001;
     float tf = static_cast<float>(t);
     if (static_cast<double>(tf) < t) tf = __uint_as_float(__float_as_uint(tf) + 1);   // round up
     tau[b] = tf;
@@ -944,11 +943,13 @@ __global__ __launch_bounds__(256) void k_rerank(CbView cb, const float *__restri
                                                 int64_t bpad, const float *__restrict__ wmin,
                                                 const uint64_t *__restrict__ wmask,
                                                 const float *__restrict__ tau,
+                                                const uint32_t *__restrict__ pair_count, uint32_t cap,
                                                 uint64_t *__restrict__ keys,
                                                 unsigned long long *__restrict__ stats) {
   const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (b >= count) return;
+  if (pair_count && *pair_count <= cap) return;          // the pair path handled the run
   float m = 3.4e38f;
   for (int64_t g = lane; g < cb.ngroups; g += WAVE) m = fminf(m, wmin[g * bpad + b]);
 #pragma unroll
@@ -985,11 +986,126 @@ __global__ __launch_bounds__(256) void k_rerank(CbView cb, const float *__restri
   }
   best = wave_min_u64(best);
   if (lane == 0) {
-    keys[b] = best;
+    atomicMin(reinterpret_cast<unsigned long long *>(keys + b), static_cast<unsigned long long>(best));
     atomicAdd(stats + 0, static_cast<unsigned long long>(ngroups_done));
     atomicAdd(stats + 1, static_cast<unsigned long long>(nrows_done));
     atomicMax(stats + 2, static_cast<unsigned long long>(ngroups_done));
   }
+}
+
+// =====================================================================================
+// K2s / K2p: the usual case of the re-rank, row-granular.  K2s (one wave per sample) finds
+// the groups within tau of the global minimum and appends the masked rows as
+// (sample, row) pairs to one list; K2p (one lane per pair) recomputes each pair's distance
+// with the reference's arithmetic (dims in order, sub/mul/add) and folds the key into
+// keys[sample] with a 64-bit atomic min.  If the list overflows (pathological codebooks: huge
+// numbers of near-ties) K2p does nothing and K2r above re-ranks the whole run group by group.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_rerank_select(CbView cb, int64_t count, int64_t bpad,
+                                                       const float *__restrict__ wmin,
+                                                       const uint64_t *__restrict__ wmask,
+                                                       const float *__restrict__ tau,
+                                                       uint32_t cap, uint2 *__restrict__ pairs,
+                                                       uint32_t *__restrict__ pair_count,
+                                                       unsigned long long *__restrict__ stats) {
+  // workgroup = 32 consecutive samples (one 128-byte line of wmin) x 8 interleaved group phases
+  __shared__ float s_min[8][32];
+  const int tid = threadIdx.x, bx = tid & 31, gy = tid >> 5, lane = tid & 63;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 32 + bx;
+  float m = 3.4e38f;
+  if (b < bpad)
+    for (int64_t g = gy; g < cb.ngroups; g += 8) m = fminf(m, wmin[g * bpad + b]);
+  s_min[gy][bx] = m;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; k++) m = fminf(m, s_min[k][bx]);
+  const bool live = b < count;
+  const float thr = live ? m + tau[b] : -3.4e38f;
+  unsigned ngr = 0, nrow = 0;
+  for (int64_t g0 = 0; g0 < cb.ngroups; g0 += 8) {
+    const int64_t g = g0 + gy;
+    unsigned long long mask = 0;
+    if (live && g < cb.ngroups && wmin[g * bpad + b] <= thr) {
+      mask = wmask[g * bpad + b];
+      // drop padding rows of the last group: bit 32h+16i+r is row 32i + (r&3) + 8(r>>2) + 4h
+      if ((g + 1) * WAVE > cb.n) {
+        unsigned long long keep = 0;
+        for (int t = 0; t < 64; t++) {
+          const int h = t >> 5, i = (t >> 4) & 1, r = t & 15;
+          if (g * WAVE + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h < cb.n) keep |= 1ull << t;
+        }
+        mask &= keep;
+      }
+    }
+    const unsigned n = __popcll(mask);
+    if (__ballot(n != 0) == 0) continue;                 // wave-uniform
+    // wave-aggregated reservation in the pair list
+    unsigned pre = n;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const unsigned v = __shfl_up(pre, off, WAVE);
+      if (lane >= off) pre += v;
+    }
+    const unsigned wave_total = __shfl(pre, WAVE - 1, WAVE);
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(pair_count, wave_total);
+    base = __shfl(base, 0, WAVE) + pre - n;
+    if (n) {
+      ngr++; nrow += n;
+      unsigned at = base;
+      unsigned long long mm = mask;
+      while (mm) {
+        const int t = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        const int h = t >> 5, i = (t >> 4) & 1, r = t & 15;
+        if (at < cap)
+          pairs[at] = make_uint2(static_cast<uint32_t>(b),
+                                 static_cast<uint32_t>(g * WAVE + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h));
+        at++;
+      }
+    }
+  }
+  // statistics (per sample: sum the 8 phases through LDS)
+  __syncthreads();
+  s_min[gy][bx] = __uint_as_float(ngr);
+  __syncthreads();
+  if (gy == 0 && live) {
+    unsigned tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) tot += __float_as_uint(s_min[k][bx]);
+    atomicMax(stats + 2, static_cast<unsigned long long>(tot));
+  }
+  unsigned long long a0 = ngr, a1 = nrow;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { a0 += __shfl_xor(a0, off, WAVE); a1 += __shfl_xor(a1, off, WAVE); }
+  if (lane == 0 && a1) { atomicAdd(stats + 0, a0); atomicAdd(stats + 1, a1); }
+}
+
+__global__ __launch_bounds__(256) void k_rerank_pairs(CbView cb, const float *__restrict__ rows,
+                                                      int64_t n_rows, int64_t first, uint32_t cap,
+                                                      const uint2 *__restrict__ pairs,
+                                                      const uint32_t *__restrict__ pair_count,
+                                                      uint64_t *__restrict__ keys) {
+  const uint32_t np = *pair_count;
+  if (np > cap) return;                                  // list overflowed: K2r does the whole run
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= np) return;
+  const uint2 pr = pairs[p];
+  const int64_t row = pr.y;
+  const float4 *crow = reinterpret_cast<const float4 *>(cb.tiles) + ((row >> 6) * cb.d4) * WAVE + (row & 63);
+  const float *x = rows + ((first + pr.x) % n_rows) * cb.d;
+  const bool vec = (cb.d & 3) == 0;
+  float acc = 0.0f;
+  for (int q = 0; q < cb.d4; q++) {
+    const float4 c = crow[static_cast<int64_t>(q) * WAVE];
+    const float4 xv = vec ? reinterpret_cast<const float4 *>(x)[q] : load_x4<false>(x, q, cb.d);
+    acc = sq_acc(acc, c.x, xv.x);
+    acc = sq_acc(acc, c.y, xv.y);
+    acc = sq_acc(acc, c.z, xv.z);
+    acc = sq_acc(acc, c.w, xv.w);
+  }
+  const uint64_t k = make_key(acc, static_cast<uint32_t>(row + cb.row_offset));
+  atomicMin(reinterpret_cast<unsigned long long *>(keys + pr.x), static_cast<unsigned long long>(k));
 }
 
 // =====================================================================================

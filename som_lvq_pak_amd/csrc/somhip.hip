@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -61,12 +62,15 @@ enum KernelId {
   KID_RERANK,
   KID_NORMS,
   KID_MEMBERS,
+  KID_RERANK_SELECT,
+  KID_RERANK_PAIRS,
   KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {
     "k_scan_exact", "k_som_update_run", "k_som_online_step", "k_lvq_online_step",
     "k_pack_samples", "k_merge_topk", "k_scan_masked", "k_layout", "k_decode_winners",
-    "k_dist_mfma", "k_rerank", "k_norms_tau", "k_som_members"};
+    "k_dist_mfma", "k_rerank", "k_norms_tau", "k_som_members",
+    "k_rerank_select", "k_rerank_pairs"};
 extern "C" int somhip_kernel_count(void) { return KID_COUNT; }
 extern "C" const char *somhip_kernel_name(int i) { return (i >= 0 && i < KID_COUNT) ? kKernelNames[i] : ""; }
 
@@ -75,6 +79,7 @@ struct somhip_engine {
   hipStream_t stream = nullptr;
   bool timing = false;
   int scan_mode = SOMHIP_SCAN_MFMA;
+  double tau_scale = 1.0;                    // >= 1: widen the pre-filter window (experiments only)
   unsigned long long *d_stats = nullptr;     // [4] re-rank statistics (device)
   uint64_t samples_searched = 0;
   struct Pending { int kid; hipEvent_t a, b; };
@@ -151,6 +156,7 @@ extern "C" int somhip_engine_create(int device, somhip_engine **out) {
   somhip_engine *e = new somhip_engine();
   e->device = device;
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  if (const char *ts = getenv("SOMHIP_TAU_SCALE")) { double v = atof(ts); if (v >= 1.0) e->tau_scale = v; }
   HIPCHK(hipMalloc((void **)&e->d_stats, 8 * sizeof(unsigned long long)));
   HIPCHK(hipMemset(e->d_stats, 0, 8 * sizeof(unsigned long long)));
   *out = e;
@@ -397,6 +403,14 @@ static int check_pair(const somhip_codebook *cb, const somhip_dataset *ds, const
 
 constexpr int64_t MFMA_MIN_SAMPLES = 32;
 
+// Bound on |s~ + ||x||^2 - d| / (||x|| + ||c||)^2: fp32 MFMA GEMM form vs the
+// reference's direct form, u = 2^-24, gamma_k = k u / (1 - k u):  2 * gamma_{d+2}.
+static double prefilter_err_coeff(const somhip_engine *e, int d) {
+  const double u = 5.9604644775390625e-08;
+  const double k = (d + 2) * u;
+  return 2.0 * (k / (1.0 - k)) * e->tau_scale;
+}
+
 // MFMA pre-filter + exact re-rank (kernels.hpp K2/K2r); xt = packed sample tiles of the run
 static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
                           const float4 *xt, int64_t nsb, uint64_t *d_keys) {
@@ -416,7 +430,8 @@ static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first
     hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((cb->v.ngroups + 3) / 4)), dim3(256), 0, e->stream,
                        cb->v, cb->d_cn, cb->d_cnmax);
     hipLaunchKernelGGL(k_sample_tau, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, e->stream,
-                       ds->d_rows, ds->n, ds->d, first, count, (const unsigned int *)cb->d_cnmax, (float *)dtau);
+                       ds->d_rows, ds->n, ds->d, first, count, (const unsigned int *)cb->d_cnmax,
+                       prefilter_err_coeff(e, ds->d), (float *)dtau);
   }
   HIPCHK(hipGetLastError());
   {
@@ -426,11 +441,30 @@ static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first
                        (const float *)dtau, count, bpad, (float *)dwmin, (uint64_t *)dwmask);
   }
   HIPCHK(hipGetLastError());
+  // exact re-rank: row-granular pair path for the usual few candidates, group-granular
+  // k_rerank for flagged samples (too many candidates / list full)
+  const uint32_t cap = (uint32_t)std::min<int64_t>(64 * count + 4096, 0x7FFFFFF0);
+  void *dpairs;
+  CHK(engine_scratch(e, 11, sizeof(uint2) * (size_t)cap + 16, &dpairs));
+  uint32_t *d_paircount = reinterpret_cast<uint32_t *>(e->d_stats + 6);
+  HIPCHK(hipMemsetAsync(d_paircount, 0, sizeof(uint32_t), e->stream));
+  {
+    LaunchTimer t(e, KID_RERANK_SELECT);
+    hipLaunchKernelGGL(k_rerank_select, dim3((unsigned)(bpad / 32)), dim3(256), 0, e->stream, cb->v, count, bpad,
+                       (const float *)dwmin, (const uint64_t *)dwmask, (const float *)dtau, cap, (uint2 *)dpairs,
+                       d_paircount, e->d_stats);
+  }
+  {
+    LaunchTimer t(e, KID_RERANK_PAIRS);
+    hipLaunchKernelGGL(k_rerank_pairs, dim3((cap + 255) / 256), dim3(256), 0, e->stream, cb->v, ds->d_rows, ds->n,
+                       first, cap, (const uint2 *)dpairs, (const uint32_t *)d_paircount, d_keys);
+  }
   {
     LaunchTimer t(e, KID_RERANK);
     hipLaunchKernelGGL(k_rerank, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, e->stream, cb->v,
                        ds->d_rows, ds->n, first, count, bpad, (const float *)dwmin,
-                       (const uint64_t *)dwmask, (const float *)dtau, d_keys, e->d_stats);
+                       (const uint64_t *)dwmask, (const float *)dtau, (const uint32_t *)d_paircount, cap, d_keys,
+                       e->d_stats);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -670,7 +704,13 @@ static int som_update_run(somhip_codebook *cb, somhip_dataset *ds, int64_t data_
                           const uint64_t *d_keys, const StepScalars *d_sc) {
   somhip_engine *e = cb->e;
   const bool G = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN, M = ds->d_mask != nullptr;
-  constexpr int QW = 8, TB = 32;
+#ifndef SOMHIP_UPD_QW
+#define SOMHIP_UPD_QW 8
+#endif
+#ifndef SOMHIP_UPD_TB
+#define SOMHIP_UPD_TB 32
+#endif
+  constexpr int QW = SOMHIP_UPD_QW, TB = SOMHIP_UPD_TB;
   void *dbxy, *dcnt, *dent;
   CHK(engine_scratch(e, 8, sizeof(int2) * (size_t)count, &dbxy));
   CHK(engine_scratch(e, 9, sizeof(uint32_t) * (size_t)cb->v.ngroups, &dcnt));
