@@ -53,14 +53,23 @@ int  somhip_engine_sync(somhip_engine *e);
  *   SOMHIP_SCAN_DIRECT  direct-form fp32 scan on the vector ALU (the reference's arithmetic)
  *   SOMHIP_SCAN_MFMA    fp32-MFMA distance GEMM as a pre-filter with a rigorous error bound +
  *                       exact re-rank of the surviving rows by the direct-form arithmetic
- * Both return bit-identical winners; MFMA is the default where it applies (no masks). */
-enum { SOMHIP_SCAN_DIRECT = 0, SOMHIP_SCAN_MFMA = 1 };
+ *   SOMHIP_SCAN_MFMA_BF16  the same with the GEMM on the bf16 matrix pipe (operands split
+ *                       hi + lo, three MFMAs per K-step; wider bound, same exact re-rank)
+ * All return bit-identical winners; the MFMA forms apply where there are no masks (default:
+ * SOMHIP_SCAN_MFMA_BF16). */
+enum { SOMHIP_SCAN_DIRECT = 0, SOMHIP_SCAN_MFMA = 1, SOMHIP_SCAN_MFMA_BF16 = 2 };
 int  somhip_engine_set_scan_mode(somhip_engine *e, int mode);
 /* cumulative re-rank statistics of the MFMA path since engine creation:
  * out[0] = row groups re-ranked, out[1] = rows re-ranked, out[2] = max groups for one sample,
  * out[3] = samples searched, out[4] = (row, iteration) updates applied by mini-batch runs,
  * out[5] = (row group, iteration) pairs with at least one update */
 int  somhip_scan_stats(somhip_engine *e, uint64_t out[6]);
+
+/* diagnostics (tests): run only the pre-filter of the current scan mode on data rows
+ * [first, first+count) and return its raw outputs: wmin[ngroups][*bpad] (group minima of
+ * s~ = ||c||^2 - 2<c,x>) and tau[count].  wmin must hold ngroups * (count rounded up to 32). */
+int  somhip_debug_prefilter(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
+                            float *wmin, float *tau, int64_t *bpad);
 
 /* ---- codebook mirror -------------------------------------------------------
  * rows: host, row-major [n_rows][dim] fp32, row k = list position k of the

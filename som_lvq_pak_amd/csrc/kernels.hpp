@@ -386,6 +386,57 @@ __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int
   }
 }
 
+// Epilogue shared by the fp32 and the split-bf16 distance GEMMs (same C/D register layout):
+// s~ = cn - 2 dot, group minimum per sample, mask of rows within tau of it.
+// Accumulator register r of block i is code row 32 i + (r&3) + 8 (r>>2) + 4 half; the lane's
+// column is sample (lane & 31) of tile j.
+__device__ __forceinline__ void prefilter_epilogue(const CbView &cb, f32x16 (&acc)[2][2], int64_t g,
+                                                   int64_t st_first, int64_t nst, int lane,
+                                                   const float *__restrict__ cn,
+                                                   const float *__restrict__ tau, int64_t count,
+                                                   int64_t bpad, float *__restrict__ wmin,
+                                                   uint64_t *__restrict__ wmask) {
+  if (g >= cb.ngroups) return;
+  const int half = lane >> 5, l31 = lane & 31;
+  float4 cnv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      cnv[i][k] = *reinterpret_cast<const float4 *>(cn + g * 64 + 32 * i + 8 * k + 4 * half);
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int64_t st = st_first + j;
+    if (st >= nst) continue;
+    const int64_t b = st * 32 + l31;
+    float sv[2][16];
+    float m = 3.4e38f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float4 c4 = cnv[i][r >> 2];
+        const float cnr = (r & 3) == 0 ? c4.x : (r & 3) == 1 ? c4.y : (r & 3) == 2 ? c4.z : c4.w;
+        const float v = cnr - 2.0f * acc[i][j][r];
+        sv[i][r] = v;
+        m = fminf(m, v);
+      }
+    m = fminf(m, __shfl_xor(m, 32, WAVE));
+    const float thr = m + (b < count ? tau[b] : 0.0f);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (sv[i][r] <= thr) bits |= 1u << (16 * i + r);
+    const uint32_t other = __shfl_xor(bits, 32, WAVE);
+    if (half == 0 && b < bpad) {
+      wmin[g * bpad + b] = m;
+      wmask[g * bpad + b] = static_cast<uint64_t>(bits) | (static_cast<uint64_t>(other) << 32);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void k_dist_mfma(CbView cb, const float4 *__restrict__ xt,
                                                       const float *__restrict__ cn,
                                                       const float *__restrict__ tau, int64_t count,
@@ -393,7 +444,8 @@ __global__ __launch_bounds__(256, 2) void k_dist_mfma(CbView cb, const float4 *_
                                                       uint64_t *__restrict__ wmask) {
   // [stage][ 2 groups x QB x 64 | 4 tiles x QB x 32 ] float4
   __shared__ float4 lds[2][2 * MF_QB * 64 + 4 * MF_QB * 32];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: piece maps live in SGPRs
   const int wr = wave >> 1, wc = wave & 1;
   const int half = lane >> 5, l31 = lane & 31;
   const int64_t g0 = static_cast<int64_t>(blockIdx.y) * 2;          // first row group of the WG
@@ -479,47 +531,174 @@ __global__ __launch_bounds__(256, 2) void k_dist_mfma(CbView cb, const float4 *_
     __syncthreads();
   }
 
-  // ---- epilogue: s~ = cn - 2 dot, group minimum per sample, candidate mask
-  const int64_t g = g0 + wr;
+  prefilter_epilogue(cb, acc, g0 + wr, st0 + wc * 2, nst, lane, cn, tau, count, bpad, wmin, wmask);
+}
+
+// =====================================================================================
+// K2b: the same pre-filter on the bf16 matrix pipe (16x the fp32 MFMA rate) by operand
+// splitting: v = hi + lo + r, hi = bf16(v), lo = bf16(v - hi), |r| <= 2^-16 |v|, and
+//     <c, x>  ~  <c_hi, x_hi> + <c_hi, x_lo> + <c_lo, x_hi>          (3 MFMAs per K-step)
+// Products of two bf16 are exact in fp32; what is lost is the dropped lo*lo / r terms
+// (<= 3.1 * 2^-16 ||x|| ||c||) and the fp32 accumulation of 3d terms, both added to the
+// error coefficient tau is built from (somhip.hip prefilter_err_coeff), so the exact
+// re-rank downstream still returns the reference's bits.  Codes and samples are kept as
+// bf16 tiles [group|tile][kb = dim/8][row][8] (16 B per row and k-block = one MFMA operand).
+// =====================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BF_KB = 8;                  // k-blocks (of 8 dims) per stage: 64 dims
+
+__device__ __forceinline__ uint32_t f2bf_rn(float v) {          // finite inputs
+  uint32_t u = __float_as_uint(v);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split_bf16(float v, uint32_t &hi, uint32_t &lo) {
+  hi = f2bf_rn(v);
+  const float r = v - __uint_as_float(hi << 16);                // exact
+  lo = f2bf_rn(r);
+}
+__device__ __forceinline__ void split8(const float4 a, const float4 b, uint4 &hi, uint4 &lo) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint32_t h[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) split_bf16(v[j], h[j], l[j]);
+  hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+  lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+// squared norms (fp32, as k_row_norms) + bf16 hi/lo tiles of the codebook, one pass
+__global__ void k_prep_codes_bf16(CbView cb, int d8, float *__restrict__ cn,
+                                  unsigned int *__restrict__ cn_max_bits, uint4 *__restrict__ chi,
+                                  uint4 *__restrict__ clo) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave;
   if (g >= cb.ngroups) return;
-  // accumulator register r of block i is code row 32 i + (r&3) + 8 (r>>2) + 4 half
-  float4 cnv[2][4];
+  float acc = 0.0f;
+  for (int kb = 0; kb < d8; kb++) {
+    const float4 a = *tile_ptr(cb, g, 2 * kb, lane);
+    const float4 b = (2 * kb + 1 < cb.d4) ? *tile_ptr(cb, g, 2 * kb + 1, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc += a.x * a.x; acc += a.y * a.y; acc += a.z * a.z; acc += a.w * a.w;
+    acc += b.x * b.x; acc += b.y * b.y; acc += b.z * b.z; acc += b.w * b.w;
+    uint4 hi, lo;
+    split8(a, b, hi, lo);
+    chi[(g * d8 + kb) * WAVE + lane] = hi;
+    clo[(g * d8 + kb) * WAVE + lane] = lo;
+  }
+  const int64_t row = g * WAVE + lane;
+  cn[row] = row < cb.n ? acc : 3.0e38f;
+  float m = row < cb.n ? acc : 0.0f;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, WAVE));
+  if (lane == 0) atomicMax(cn_max_bits, __float_as_uint(m));
+}
+
+// a run of samples -> bf16 hi/lo sample tiles xt[sb][kb][32][8]
+__global__ void k_pack_samples_bf16(const float *__restrict__ rows, int64_t n_rows, int d, int d8,
+                                    int64_t first, int64_t count, uint4 *__restrict__ xhi,
+                                    uint4 *__restrict__ xlo) {
+  const int64_t sb = blockIdx.x;
+  for (int e = threadIdx.x; e < d8 * 32; e += blockDim.x) {
+    const int kb = e / 32, sidx = e % 32;
+    const int64_t smp = sb * 32 + sidx;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (smp < count) {
+      const float *x = rows + ((first + smp) % n_rows) * d;
+#pragma unroll
+      for (int j = 0; j < 8; j++) if (kb * 8 + j < d) v[j] = x[kb * 8 + j];
+    }
+    uint4 hi, lo;
+    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+    xhi[(sb * d8 + kb) * 32 + sidx] = hi;
+    xlo[(sb * d8 + kb) * 32 + sidx] = lo;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_dist_mfma_bf16(CbView cb, int d8,
+                                                           const uint4 *__restrict__ chi,
+                                                           const uint4 *__restrict__ clo,
+                                                           const uint4 *__restrict__ xhi,
+                                                           const uint4 *__restrict__ xlo,
+                                                           const float *__restrict__ cn,
+                                                           const float *__restrict__ tau, int64_t count,
+                                                           int64_t bpad, float *__restrict__ wmin,
+                                                           uint64_t *__restrict__ wmask) {
+  // one stage: codes hi [2][KB][64] | codes lo | samples hi [4][KB][32] | samples lo   (uint4 each)
+  constexpr int CH = 0, CL = 2 * BF_KB * 64, XH = 2 * CL, XL = XH + 4 * BF_KB * 32, TOT = XL + 4 * BF_KB * 32;
+  __shared__ uint4 lds[TOT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: piece maps live in SGPRs
+  const int wr = wave >> 1, wc = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int64_t g0 = static_cast<int64_t>(blockIdx.y) * 2;
+  const int64_t st0 = static_cast<int64_t>(blockIdx.x) * 4;
+  const int64_t nst = bpad / 32;
+
+  // 64 pieces of 1 KiB per stage, 16 per wave
+  const uint4 *src[16];
+  int dst[16], stride[16], kbl[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int p = wave * 16 + i;
+    if (p < 32) {
+      const int arr = p >> 4, gi = (p >> 3) & 1, kb = p & 7;
+      const int64_t g = g0 + gi < cb.ngroups ? g0 + gi : cb.ngroups - 1;
+      src[i] = (arr ? clo : chi) + (g * d8 + kb) * 64 + lane;
+      dst[i] = (arr ? CL : CH) + (gi * BF_KB + kb) * 64 + lane;
+      stride[i] = BF_KB * 64;
+      kbl[i] = kb;
+    } else {
+      const int pp = p - 32, arr = pp >> 4, ti = (pp >> 2) & 3, kp = pp & 3;
+      const int64_t st = st0 + ti < nst ? st0 + ti : nst - 1;
+      src[i] = (arr ? xlo : xhi) + (st * d8 + 2 * kp) * 32 + lane;
+      dst[i] = (arr ? XL : XH) + (ti * BF_KB + 2 * kp) * 32 + lane;
+      stride[i] = BF_KB * 32;
+      kbl[i] = 2 * kp + half;
+    }
+  }
+  const int nstage = (d8 + BF_KB - 1) / BF_KB;
+  auto stage_load = [&](uint4 (&r)[16], int s) {
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      r[i] = (s * BF_KB + kbl[i] < d8) ? src[i][static_cast<int64_t>(s) * stride[i]] : make_uint4(0u, 0u, 0u, 0u);
+  };
+
+  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-      cnv[i][k] = *reinterpret_cast<const float4 *>(cn + g * 64 + 32 * i + 8 * k + 4 * half);
+    for (int j = 0; j < 2; j++)
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int64_t st = st0 + wc * 2 + j;
-    if (st >= nst) continue;
-    const int64_t b = st * 32 + l31;
-    float sv[2][16];
-    float m = 3.4e38f;
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+  uint4 regs[16];
+  stage_load(regs, 0);
+  for (int s = 0; s < nstage; s++) {
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 16; i++) lds[dst[i]] = regs[i];
+    __syncthreads();
+    if (s + 1 < nstage) stage_load(regs, s + 1);
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float4 c4 = cnv[i][r >> 2];
-        const float cnr = (r & 3) == 0 ? c4.x : (r & 3) == 1 ? c4.y : (r & 3) == 2 ? c4.z : c4.w;
-        const float v = cnr - 2.0f * acc[i][j][r];
-        sv[i][r] = v;
-        m = fminf(m, v);
+    for (int m = 0; m < BF_KB / 2; m++) {
+      const int kb = 2 * m + half;
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        ah[i] = __builtin_bit_cast(bf16x8, lds[CH + (wr * BF_KB + kb) * 64 + 32 * i + l31]);
+        al[i] = __builtin_bit_cast(bf16x8, lds[CL + (wr * BF_KB + kb) * 64 + 32 * i + l31]);
+        bh[i] = __builtin_bit_cast(bf16x8, lds[XH + ((wc * 2 + i) * BF_KB + kb) * 32 + l31]);
+        bl[i] = __builtin_bit_cast(bf16x8, lds[XL + ((wc * 2 + i) * BF_KB + kb) * 32 + l31]);
       }
-    m = fminf(m, __shfl_xor(m, 32, WAVE));
-    const float thr = m + (b < count ? tau[b] : 0.0f);
-    uint32_t bits = 0;
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+      for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int r = 0; r < 16; r++)
-        if (sv[i][r] <= thr) bits |= 1u << (16 * i + r);
-    const uint32_t other = __shfl_xor(bits, 32, WAVE);
-    if (half == 0 && b < bpad) {
-      wmin[g * bpad + b] = m;
-      wmask[g * bpad + b] = static_cast<uint64_t>(bits) | (static_cast<uint64_t>(other) << 32);
+        for (int j = 0; j < 2; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        }
     }
+    __syncthreads();
   }
+  prefilter_epilogue(cb, acc, g0 + wr, st0 + wc * 2, nst, lane, cn, tau, count, bpad, wmin, wmask);
 }
 
 // =====================================================================================

@@ -64,13 +64,14 @@ enum KernelId {
   KID_MEMBERS,
   KID_RERANK_SELECT,
   KID_RERANK_PAIRS,
+  KID_DIST_MFMA_BF16,
   KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {
     "k_scan_exact", "k_som_update_run", "k_som_online_step", "k_lvq_online_step",
     "k_pack_samples", "k_merge_topk", "k_scan_masked", "k_layout", "k_decode_winners",
     "k_dist_mfma", "k_rerank", "k_norms_tau", "k_som_members",
-    "k_rerank_select", "k_rerank_pairs"};
+    "k_rerank_select", "k_rerank_pairs", "k_dist_mfma_bf16"};
 extern "C" int somhip_kernel_count(void) { return KID_COUNT; }
 extern "C" const char *somhip_kernel_name(int i) { return (i >= 0 && i < KID_COUNT) ? kKernelNames[i] : ""; }
 
@@ -78,7 +79,7 @@ struct somhip_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   bool timing = false;
-  int scan_mode = SOMHIP_SCAN_MFMA;
+  int scan_mode = SOMHIP_SCAN_MFMA_BF16;
   double tau_scale = 1.0;                    // >= 1: widen the pre-filter window (experiments only)
   unsigned long long *d_stats = nullptr;     // [4] re-rank statistics (device)
   uint64_t samples_searched = 0;
@@ -180,7 +181,7 @@ extern "C" int somhip_engine_sync(somhip_engine *e) {
   return 0;
 }
 extern "C" int somhip_engine_set_scan_mode(somhip_engine *e, int mode) {
-  if (mode != SOMHIP_SCAN_DIRECT && mode != SOMHIP_SCAN_MFMA) return fail("somhip_engine_set_scan_mode: bad mode %d", mode);
+  if (mode != SOMHIP_SCAN_DIRECT && mode != SOMHIP_SCAN_MFMA && mode != SOMHIP_SCAN_MFMA_BF16) return fail("somhip_engine_set_scan_mode: bad mode %d", mode);
   e->scan_mode = mode;
   return 0;
 }
@@ -237,6 +238,7 @@ struct somhip_codebook {
   float *d_talpha = nullptr;       // [n] OLVQ1 rates
   float *d_cn = nullptr;           // [ngroups*64] squared row norms (MFMA pre-filter)
   unsigned int *d_cnmax = nullptr; // bits of max squared norm
+  uint4 *d_chi = nullptr, *d_clo = nullptr;   // bf16 hi/lo tiles [ngroups][d8][64] (bf16 pre-filter)
 };
 struct somhip_dataset {
   somhip_engine *e = nullptr;
@@ -331,6 +333,8 @@ extern "C" void somhip_codebook_destroy(somhip_codebook *cb) {
   if (cb->d_talpha) (void)hipFree(cb->d_talpha);
   if (cb->d_cn) (void)hipFree(cb->d_cn);
   if (cb->d_cnmax) (void)hipFree(cb->d_cnmax);
+  if (cb->d_chi) (void)hipFree(cb->d_chi);
+  if (cb->d_clo) (void)hipFree(cb->d_clo);
   delete cb;
 }
 
@@ -405,42 +409,84 @@ constexpr int64_t MFMA_MIN_SAMPLES = 32;
 
 // Bound on |s~ + ||x||^2 - d| / (||x|| + ||c||)^2: fp32 MFMA GEMM form vs the
 // reference's direct form, u = 2^-24, gamma_k = k u / (1 - k u):  2 * gamma_{d+2}.
+// Split-bf16 form (kernels.hpp K2b): the dot product loses at most 3.1 * 2^-16 ||x|| ||c|| to the
+// dropped lo*lo / residual terms and accumulates 3d exact products in fp32 -- bounded here with
+// a factor 2 on the accumulation (no assumption on the matrix pipe's internal summation order or
+// rounding mode beyond "error of a sum of k terms <= 2 gamma_k * sum |terms|"), sum |terms| <=
+// 1.02 ||x|| ||c||.  The cn term and the direct-form term are as in the fp32 case.
 static double prefilter_err_coeff(const somhip_engine *e, int d) {
   const double u = 5.9604644775390625e-08;
   const double k = (d + 2) * u;
-  return 2.0 * (k / (1.0 - k)) * e->tau_scale;
+  const double gam = k / (1.0 - k);
+  if (e->scan_mode == SOMHIP_SCAN_MFMA_BF16) {
+    const double k3 = 3.0 * (d + 2) * u;
+    const double dot = 2.0 * (k3 / (1.0 - k3)) * 1.02 + 3.1 / 65536.0 + u;
+    return (std::max(dot, gam) + gam) * e->tau_scale;
+  }
+  return 2.0 * gam * e->tau_scale;
 }
 
-// MFMA pre-filter + exact re-rank (kernels.hpp K2/K2r); xt = packed sample tiles of the run
+// MFMA pre-filter + exact re-rank (kernels.hpp K2/K2b/K2s/K2p/K2r)
 static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
-                          const float4 *xt, int64_t nsb, uint64_t *d_keys) {
+                          int64_t nsb, uint64_t *d_keys, bool prefilter_only = false,
+                          float **out_wmin = nullptr, float **out_tau = nullptr) {
   somhip_engine *e = cb->e;
   const int64_t bpad = nsb * SCAN_S;
+  const bool bf16 = e->scan_mode == SOMHIP_SCAN_MFMA_BF16;
+  const int d8 = (cb->v.d4 + 1) / 2;
   if (!cb->d_cn) {
     HIPCHK(hipMalloc((void **)&cb->d_cn, sizeof(float) * (size_t)cb->v.ngroups * WAVE));
     HIPCHK(hipMalloc((void **)&cb->d_cnmax, sizeof(unsigned int)));
   }
-  void *dtau, *dwmin, *dwmask;
+  if (bf16 && !cb->d_chi) {
+    HIPCHK(hipMalloc((void **)&cb->d_chi, sizeof(uint4) * (size_t)cb->v.ngroups * d8 * WAVE));
+    HIPCHK(hipMalloc((void **)&cb->d_clo, sizeof(uint4) * (size_t)cb->v.ngroups * d8 * WAVE));
+  }
+  void *dtau, *dwmin, *dwmask, *xt;
   CHK(engine_scratch(e, 5, sizeof(float) * (size_t)bpad, &dtau));
   CHK(engine_scratch(e, 6, sizeof(float) * (size_t)cb->v.ngroups * bpad, &dwmin));
   CHK(engine_scratch(e, 7, sizeof(uint64_t) * (size_t)cb->v.ngroups * bpad, &dwmask));
+  // sample tiles: fp32 xt[sb][q][32][4], or bf16 hi | lo xt[sb][kb][32][8]
+  const size_t xt_bytes = bf16 ? 2 * sizeof(uint4) * (size_t)nsb * d8 * 32 : sizeof(float4) * (size_t)nsb * cb->v.d4 * SCAN_S;
+  CHK(engine_scratch(e, 1, xt_bytes, &xt));
+  uint4 *xhi = (uint4 *)xt, *xlo = xhi + (size_t)nsb * d8 * 32;
+  {
+    LaunchTimer t(e, KID_PACK_SAMPLES);
+    if (bf16)
+      hipLaunchKernelGGL(k_pack_samples_bf16, dim3((unsigned)nsb), dim3(256), 0, e->stream, ds->d_rows, ds->n, ds->d,
+                         d8, first, count, xhi, xlo);
+    else
+      hipLaunchKernelGGL(k_pack_samples<SCAN_S>, dim3((unsigned)nsb), dim3(256), 0, e->stream, ds->d_rows, ds->n,
+                         ds->d, cb->v.d4, first, count, (float4 *)xt);
+  }
+  HIPCHK(hipGetLastError());
   HIPCHK(hipMemsetAsync(cb->d_cnmax, 0, sizeof(unsigned int), e->stream));
   {
     LaunchTimer t(e, KID_NORMS);
-    hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((cb->v.ngroups + 3) / 4)), dim3(256), 0, e->stream,
-                       cb->v, cb->d_cn, cb->d_cnmax);
+    if (bf16)
+      hipLaunchKernelGGL(k_prep_codes_bf16, dim3((unsigned)((cb->v.ngroups + 3) / 4)), dim3(256), 0, e->stream,
+                         cb->v, d8, cb->d_cn, cb->d_cnmax, cb->d_chi, cb->d_clo);
+    else
+      hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((cb->v.ngroups + 3) / 4)), dim3(256), 0, e->stream,
+                         cb->v, cb->d_cn, cb->d_cnmax);
     hipLaunchKernelGGL(k_sample_tau, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, e->stream,
                        ds->d_rows, ds->n, ds->d, first, count, (const unsigned int *)cb->d_cnmax,
                        prefilter_err_coeff(e, ds->d), (float *)dtau);
   }
   HIPCHK(hipGetLastError());
   {
-    LaunchTimer t(e, KID_DIST_MFMA);
+    LaunchTimer t(e, bf16 ? KID_DIST_MFMA_BF16 : KID_DIST_MFMA);
     dim3 grid((unsigned)((nsb + 3) / 4), (unsigned)((cb->v.ngroups + 1) / 2));
-    hipLaunchKernelGGL(k_dist_mfma, grid, dim3(256), 0, e->stream, cb->v, xt, (const float *)cb->d_cn,
-                       (const float *)dtau, count, bpad, (float *)dwmin, (uint64_t *)dwmask);
+    if (bf16)
+      hipLaunchKernelGGL(k_dist_mfma_bf16, grid, dim3(256), 0, e->stream, cb->v, d8, (const uint4 *)cb->d_chi,
+                         (const uint4 *)cb->d_clo, (const uint4 *)xhi, (const uint4 *)xlo, (const float *)cb->d_cn,
+                         (const float *)dtau, count, bpad, (float *)dwmin, (uint64_t *)dwmask);
+    else
+      hipLaunchKernelGGL(k_dist_mfma, grid, dim3(256), 0, e->stream, cb->v, (const float4 *)xt, (const float *)cb->d_cn,
+                         (const float *)dtau, count, bpad, (float *)dwmin, (uint64_t *)dwmask);
   }
   HIPCHK(hipGetLastError());
+  if (prefilter_only) { *out_wmin = (float *)dwmin; *out_tau = (float *)dtau; return 0; }
   // exact re-rank: row-granular pair path for the usual few candidates, group-granular
   // k_rerank for flagged samples (too many candidates / list full)
   const uint32_t cap = (uint32_t)std::min<int64_t>(64 * count + 4096, 0x7FFFFFF0);
@@ -487,6 +533,9 @@ static int scan_keys_top1(somhip_codebook *cb, somhip_dataset *ds, int64_t first
     return 0;
   }
   int64_t nsb = (count + SCAN_S - 1) / SCAN_S;
+  e->samples_searched += (uint64_t)count;
+  if (e->scan_mode != SOMHIP_SCAN_DIRECT && count >= MFMA_MIN_SAMPLES && cb->v.n >= 64)
+    return scan_keys_mfma(cb, ds, first, count, nsb, d_keys);
   void *xt;
   CHK(engine_scratch(e, 1, sizeof(float4) * (size_t)nsb * cb->v.d4 * SCAN_S, &xt));
   {
@@ -495,9 +544,6 @@ static int scan_keys_top1(somhip_codebook *cb, somhip_dataset *ds, int64_t first
                        ds->d_rows, ds->n, ds->d, cb->v.d4, first, count, (float4 *)xt);
   }
   HIPCHK(hipGetLastError());
-  e->samples_searched += (uint64_t)count;
-  if (e->scan_mode == SOMHIP_SCAN_MFMA && count >= MFMA_MIN_SAMPLES && cb->v.n >= 64)
-    return scan_keys_mfma(cb, ds, first, count, (const float4 *)xt, nsb, d_keys);
   {
     LaunchTimer t(e, KID_SCAN_EXACT);
     dim3 grid((unsigned)nsb, (unsigned)((cb->v.ngroups + 3) / 4));
@@ -536,6 +582,22 @@ static int scan_keys_topk(somhip_codebook *cb, somhip_dataset *ds, int64_t first
                        (const uint64_t *)part, nblk, count, d_keys);
   }
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int somhip_debug_prefilter(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
+                                      float *wmin, float *tau, int64_t *bpad) {
+  CHK(check_pair(cb, ds, "somhip_debug_prefilter"));
+  somhip_engine *e = cb->e;
+  if (e->scan_mode == SOMHIP_SCAN_DIRECT || ds->d_mask) return fail("somhip_debug_prefilter: no pre-filter in this mode");
+  HIPCHK(hipSetDevice(e->device));
+  int64_t nsb = (count + SCAN_S - 1) / SCAN_S;
+  float *dw = nullptr, *dt = nullptr;
+  CHK(scan_keys_mfma(cb, ds, first, count, nsb, nullptr, true, &dw, &dt));
+  HIPCHK(hipMemcpyAsync(wmin, dw, sizeof(float) * (size_t)cb->v.ngroups * nsb * SCAN_S, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(tau, dt, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (bpad) *bpad = nsb * SCAN_S;
   return 0;
 }
 

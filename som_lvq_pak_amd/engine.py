@@ -45,8 +45,8 @@ class Engine:
         return self.lib.somhip_engine_stream(self.h)
 
     def set_scan_mode(self, mode):
-        """'direct' or 'mfma' (see include/somhip.h)"""
-        check(self.lib.somhip_engine_set_scan_mode(self.h, {"direct": 0, "mfma": 1}[mode]))
+        """'direct', 'mfma' or 'mfma_bf16' (see include/somhip.h)"""
+        check(self.lib.somhip_engine_set_scan_mode(self.h, {"direct": 0, "mfma": 1, "mfma_bf16": 2}[mode]))
 
     def scan_stats(self):
         out = (C.c_uint64 * 6)()

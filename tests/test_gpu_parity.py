@@ -300,11 +300,11 @@ def test_mfma_prefilter_equals_direct_scan(eng, E, oracle, n, d, m):
     cb, ds = E.Codebook(eng, codes), E.Dataset(eng, x)
     oi, od, _ = oracle.winners(codes, x)
     out = {}
-    for mode in ("direct", "mfma"):
+    for mode in ("direct", "mfma", "mfma_bf16"):
         eng.set_scan_mode(mode)
         out[mode] = E.find_winners(cb, ds)
-    eng.set_scan_mode("mfma")
-    for mode in ("direct", "mfma"):
+    eng.set_scan_mode("mfma_bf16")
+    for mode in ("direct", "mfma", "mfma_bf16"):
         gi, gd, _ = out[mode]
         assert np.array_equal(gi, oi), mode
         assert np.array_equal(bits(gd), bits(od)), mode
@@ -335,13 +335,15 @@ def test_mfma_prefilter_adversarial(eng, E, oracle):
     cases.append(("clusters", cl, (cent[rs.randint(0, 5, 192)] + 1e-3 * rs.standard_normal((192, d))).astype(np.float32)))
     # samples that ARE code rows (distance exactly 0, several zero ties)
     cases.append(("zeros", dup, dup[:96]))
-    eng.set_scan_mode("mfma")
-    for name, codes, x in cases:
-        cb, ds = E.Codebook(eng, codes), E.Dataset(eng, x)
-        gi, gd, _ = E.find_winners(cb, ds)
-        oi, od, _ = oracle.winners(codes, x)
-        assert np.array_equal(gi, oi), name
-        assert np.array_equal(bits(gd), bits(od)), name
+    for mode in ("mfma", "mfma_bf16"):
+        eng.set_scan_mode(mode)
+        for name, codes, x in cases:
+            cb, ds = E.Codebook(eng, codes), E.Dataset(eng, x)
+            gi, gd, _ = E.find_winners(cb, ds)
+            oi, od, _ = oracle.winners(codes, x)
+            assert np.array_equal(gi, oi), (mode, name)
+            assert np.array_equal(bits(gd), bits(od)), (mode, name)
+    eng.set_scan_mode("mfma_bf16")
     st = eng.scan_stats()
     assert st["rows"] >= st["groups"] >= 1
 
@@ -350,11 +352,44 @@ def test_som_minibatch_mfma_and_direct_same_run(eng, E, oracle):
     x, _ = synth(61, 1500, 40)
     ini = oracle.randinit(x, 20, 13, 6)
     oc, oi, od = oracle.som_train(ini, 20, 13, 3, 1, x, 3000, 0.05, 7.0, batch=256)
-    for mode in ("direct", "mfma"):
+    for mode in ("direct", "mfma", "mfma_bf16"):
         eng.set_scan_mode(mode)
         cb, ds = E.Codebook(eng, ini, 3, 1, 20, 13), E.Dataset(eng, x)
         ti, td = E.som_train(cb, ds, 3000, 0.05, 7.0, batch=256)
         assert np.array_equal(ti, oi), mode
         assert np.array_equal(bits(td), bits(od)), mode
         assert np.array_equal(bits(cb.download()), bits(oc)), mode
-    eng.set_scan_mode("mfma")
+    eng.set_scan_mode("mfma_bf16")
+
+
+@pytest.mark.parametrize("mode", ["mfma", "mfma_bf16"])
+@pytest.mark.parametrize("d,offset,scale", [(32, 0.0, 1.0), (512, 0.0, 1.0), (512, 40.0, 1.0), (130, 1500.0, 3.0),
+                                            (1024, 5.0, 0.01)])
+def test_prefilter_error_is_inside_its_bound(eng, E, mode, d, offset, scale):
+    """the bound behind tau, measured: |s~ + ||x||^2 - d_direct| must stay below tau/2 (= delta) for
+    every (code, sample).  Each row group holds 64 copies of one vector, so the group minimum the
+    kernel returns IS that vector's s~."""
+    import ctypes as C
+    rs = np.random.RandomState(d)
+    G, B = 8, 96
+    base = (offset + scale * rs.standard_normal((G, d)) * rs.uniform(0.2, 3.0, size=(G, 1))).astype(np.float32)
+    codes = np.repeat(base, 64, axis=0)
+    x = (offset + scale * rs.standard_normal((B, d))).astype(np.float32)
+    cb, ds = E.Codebook(eng, codes), E.Dataset(eng, x)
+    eng.set_scan_mode(mode)
+    wmin = np.empty((G, B), dtype=np.float32)
+    tau = np.empty(B, dtype=np.float32)
+    bpad = C.c_int64(0)
+    E.check(eng.lib.somhip_debug_prefilter(cb.h, ds.h, 0, B, wmin.ctypes.data_as(C.POINTER(C.c_float)),
+                                           tau.ctypes.data_as(C.POINTER(C.c_float)), C.byref(bpad)))
+    eng.set_scan_mode("mfma_bf16")
+    assert bpad.value == B
+    # the reference's direct-form value, in its own arithmetic (fp32, left to right)
+    direct = np.zeros((G, B), dtype=np.float32)
+    for i in range(d):
+        t = (base[:, None, i] - x[None, :, i]).astype(np.float32)
+        direct = (direct + (t * t).astype(np.float32)).astype(np.float32)
+    xn = (x.astype(np.float64) ** 2).sum(1)
+    err = np.abs(wmin.astype(np.float64) + xn[None, :] - direct.astype(np.float64))
+    ratio = err / (0.5 * tau.astype(np.float64))[None, :]
+    assert ratio.max() < 0.5, ratio.max()            # inside the bound with a factor 2 to spare
