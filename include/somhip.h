@@ -44,7 +44,7 @@ int somhip_version(void);
 
 /* ---- engine ---- */
 int  somhip_engine_create(int device, somhip_engine **out);
-void somhip_engine_destroy(somhip_engine *e);
+void somhip_engine_destroy(somhip_engine *e);      /* destroy its codebooks / datasets first */
 /* the HIP stream all work of this engine is enqueued on (a hipStream_t) */
 void *somhip_engine_stream(somhip_engine *e);
 int  somhip_engine_sync(somhip_engine *e);

@@ -31,9 +31,19 @@ class Engine:
         check(self.lib.somhip_engine_create(device, C.byref(h)))
         self.h = h
         self.device = device
+        self._children = []          # weakrefs: mirrors must be destroyed before their engine
+
+    def _adopt(self, child):
+        import weakref
+        self._children.append(weakref.ref(child))
 
     def close(self):
         if self.h:
+            for ref in self._children:
+                child = ref()
+                if child is not None:
+                    child.close()
+            self._children = []
             self.lib.somhip_engine_destroy(self.h)
             self.h = None
 
@@ -103,6 +113,7 @@ class Codebook:
                                                 self.n, self.dim, topol, neigh, xdim, ydim, row_offset,
                                                 self.n_global, C.byref(h)))
         self.h = h
+        engine._adopt(self)
 
     def download(self):
         out = np.empty((self.n, self.dim), dtype=np.float32)
@@ -115,9 +126,9 @@ class Codebook:
         check(self.e.lib.somhip_codebook_upload(self.h, _p(rows, _lib.c_float_p)))
 
     def close(self):
-        if self.h:
+        if self.h and self.e.h:
             self.e.lib.somhip_codebook_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -148,11 +159,12 @@ class Dataset:
                                                    _p(weight, _lib.c_i16_p), _p(fixed_xy, _lib.c_i16_p),
                                                    C.byref(h)))
         self.h = h
+        engine._adopt(self)
 
     def close(self):
-        if self.h:
+        if self.h and self.e.h:
             self.e.lib.somhip_dataset_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:

@@ -1,0 +1,131 @@
+"""Full BASELINE-size checks (C4: 256x256 map, dim 512 -- far beyond what the CPU oracle can
+replay) through size-independent properties of the path:
+  * the three winner-search implementations (direct scan, fp32-MFMA and split-bf16 pre-filter +
+    exact re-rank) return identical keys;
+  * a sample that IS a code row wins that row (or an identical earlier one) at distance exactly 0;
+  * row-sharded == unsharded, bit for bit;
+  * alpha = 0 leaves every bit of the codebook unchanged;
+  * the online engine and the mini-batch engine with batch 1-sized runs agree.
+A reduced-size replay against the oracle sits beside them."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+XDIM = YDIM = 256
+DIM = 512
+B = 4096
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def world():
+    from som_lvq_pak_amd import engine as E
+    eng = E.Engine(0)
+    rs = np.random.RandomState(2024)
+    cent = (4.0 * rs.standard_normal((64, DIM))).astype(np.float32)
+    x = (cent[rs.randint(0, 64, 3 * B)] + rs.standard_normal((3 * B, DIM)).astype(np.float32)).astype(np.float32)
+    lo, hi = x.min(0), x.max(0)
+    init = (lo + (hi - lo) * rs.rand(XDIM * YDIM, DIM)).astype(np.float32)
+    init[1000] = init[77]                     # an exact duplicate row: ties must go to the lower index
+    ds = E.Dataset(eng, x)
+    yield E, eng, x, init, ds
+    eng.close()
+
+
+def _keys(E, eng, cb, ds, first, count):
+    buf = eng.device_alloc(8 * count)
+    out = np.empty(count, dtype=np.uint64)
+    E.check(eng.lib.somhip_batch_winner_keys(cb.h, ds.h, first, count, buf))
+    E.check(eng.lib.somhip_copy_to_host(eng.h, out.ctypes.data_as(C.c_void_p), buf, 8 * count))
+    eng.device_free(buf)
+    return out
+
+
+def test_c4_scan_modes_agree_and_exact_hits(world):
+    E, eng, x, init, ds = world
+    cb = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, XDIM, YDIM)
+    keys = {}
+    for mode in ("direct", "mfma", "mfma_bf16"):
+        eng.set_scan_mode(mode)
+        keys[mode] = _keys(E, eng, cb, ds, 0, B)
+    eng.set_scan_mode("mfma_bf16")
+    assert np.array_equal(keys["direct"], keys["mfma"])
+    assert np.array_equal(keys["direct"], keys["mfma_bf16"])
+    # samples equal to code rows: distance exactly 0, lowest identical row wins
+    probe = np.array([77, 1000, 5, 65535, 31337])
+    ds2 = E.Dataset(eng, np.concatenate([init[probe], x[:59]], axis=0))
+    idx, diff, _ = E.find_winners(cb, ds2)
+    assert list(idx[:5, 0]) == [77, 77, 5, 65535, 31337]
+    assert (bits(diff[:5, 0]) == 0).all()
+
+
+def test_c4_sharded_equals_unsharded_and_alpha_zero(world):
+    from som_lvq_pak_amd._lib import SomParams
+    E, eng, x, init, ds = world
+    n = XDIM * YDIM
+    length = 2 * B
+    # unsharded, two mini-batches
+    cb = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, XDIM, YDIM)
+    ti, _ = E.som_train(cb, ds, length, 0.05, 100.0, batch=B)
+    whole = cb.download()
+    assert not np.array_equal(bits(whole), bits(init))
+    # three uneven shards, explicit key merge
+    cuts = [0, 20000, 20000 + 64 * 300 + 17, n]
+    shards = [E.Codebook(eng, init[cuts[i]:cuts[i + 1]], E.TOPOL_HEXA, E.NEIGH_BUBBLE, XDIM, YDIM,
+                         row_offset=cuts[i], n_global=n) for i in range(3)]
+    kb = eng.device_alloc(8 * B)
+    p = SomParams(length, 0.05, 100.0, 1, 0, 0, B, 0, length, 0)
+    got_idx = []
+    for it0 in range(0, length, B):
+        ks = [_keys(E, eng, s, ds, it0, B) for s in shards]
+        merged = np.minimum(np.minimum(ks[0], ks[1]), ks[2])
+        got_idx.append((merged & np.uint64(0xFFFFFFFF)).astype(np.int32))
+        E.check(eng.lib.somhip_copy_to_device(eng.h, kb, merged.ctypes.data_as(C.c_void_p), 8 * B))
+        for s in shards:
+            E.check(eng.lib.somhip_som_batch_update(s.h, ds.h, C.byref(p), it0, B, it0, kb))
+    eng.sync()
+    eng.device_free(kb)
+    assert np.array_equal(np.concatenate(got_idx), ti)
+    parts = np.concatenate([s.download() for s in shards], axis=0)
+    assert np.array_equal(bits(parts), bits(whole))
+    # alpha = 0: c + 0*(x-c) == c for every element, whatever the neighbourhoods
+    cb0 = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, XDIM, YDIM)
+    E.som_train(cb0, ds, B, 0.0, 100.0, batch=B, trace=False)
+    assert np.array_equal(bits(cb0.download()), bits(init))
+
+
+def test_c4_online_equals_minibatch_of_one_and_reduced_oracle(world, oracle):
+    E, eng, x, init, ds = world
+    # online engine vs mini-batch machinery driven one sample per run (batch=1 is routed to the
+    # online kernels, so drive the two-phase primitives directly)
+    from som_lvq_pak_amd._lib import SomParams
+    steps = 24
+    cb1 = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, XDIM, YDIM)
+    t1, d1 = E.som_train(cb1, ds, steps, 0.05, 90.0, batch=1)
+    cb2 = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, XDIM, YDIM)
+    kb = eng.device_alloc(8)
+    p = SomParams(steps, 0.05, 90.0, 1, 0, 0, 1, 0, steps, 0)
+    t2 = []
+    for it in range(steps):
+        E.check(eng.lib.somhip_batch_winner_keys(cb2.h, ds.h, it, 1, kb))
+        k = np.empty(1, dtype=np.uint64)
+        E.check(eng.lib.somhip_copy_to_host(eng.h, k.ctypes.data_as(C.c_void_p), kb, 8))
+        t2.append(int(k[0] & np.uint64(0xFFFFFFFF)))
+        E.check(eng.lib.somhip_som_batch_update(cb2.h, ds.h, C.byref(p), it, 1, it, kb))
+    eng.device_free(kb)
+    assert list(t1) == t2
+    assert np.array_equal(bits(cb1.download()), bits(cb2.download()))
+    # reduced replay against the oracle: same dim, 48x32 map, 600 iterations, batch 128
+    rs = np.random.RandomState(7)
+    small = (x[:4000].min(0) + (x[:4000].max(0) - x[:4000].min(0)) * rs.rand(48 * 32, DIM)).astype(np.float32)
+    oc, oi, od = oracle.som_train(small, 48, 32, 3, 1, x[:600], 600, 0.05, 20.0, batch=128)
+    cbs, dss = E.Codebook(eng, small, 3, 1, 48, 32), E.Dataset(eng, x[:600])
+    ti, td = E.som_train(cbs, dss, 600, 0.05, 20.0, batch=128)
+    assert np.array_equal(ti, oi) and np.array_equal(bits(td), bits(od))
+    assert np.array_equal(bits(cbs.download()), bits(oc))
