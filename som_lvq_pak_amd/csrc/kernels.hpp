@@ -29,10 +29,36 @@ struct CbView {
   int64_t n;            // local rows
   int64_t ngroups;      // ceil(n / 64)
   int d, d4;
-  int64_t row_offset;   // global index of local row 0
+  int64_t row_offset;   // global unit index of the shard's first unit
   int xdim;             // map width (global)
   int topol, neigh;
+  int patch_w;          // 0: storage row s holds unit row_offset + s (the reference's order);
+                        // > 0 (= xdim/8): "8x8 patch" order -- every 64-row group is an 8x8 block of
+                        // map units, so a round neighbourhood fills whole wavefronts instead of
+                        // slivers of 64x1 strips.  Maps only, sides multiple of 8, shards on 8-row
+                        // boundaries; indices seen outside the engine are always unit indices.
 };
+
+// global unit index (= the reference's row index, datafile.c:781,836) of local storage row `row`
+__device__ __forceinline__ uint32_t unit_of_row(const CbView &cb, int64_t row) {
+  if (cb.patch_w == 0) return static_cast<uint32_t>(row + cb.row_offset);
+  const uint32_t p = static_cast<uint32_t>(row >> 6), i = static_cast<uint32_t>(row) & 63u;
+  const uint32_t px = p % static_cast<uint32_t>(cb.patch_w), py = p / static_cast<uint32_t>(cb.patch_w);
+  return static_cast<uint32_t>(cb.row_offset) + (py * 8 + (i >> 3)) * static_cast<uint32_t>(cb.xdim) + px * 8 + (i & 7);
+}
+// lattice coordinates of local storage row `row` (som_rout.c:493-494: x = unit % xdim, y = unit / xdim)
+__device__ __forceinline__ void txty_of_row(const CbView &cb, int64_t row, int &tx, int &ty) {
+  const uint32_t xd = static_cast<uint32_t>(cb.xdim);
+  if (cb.patch_w == 0) {
+    const uint32_t u = static_cast<uint32_t>(row + cb.row_offset);
+    tx = static_cast<int>(u % xd); ty = static_cast<int>(u / xd);
+    return;
+  }
+  const uint32_t p = static_cast<uint32_t>(row >> 6), i = static_cast<uint32_t>(row) & 63u;
+  const uint32_t px = p % static_cast<uint32_t>(cb.patch_w), py = p / static_cast<uint32_t>(cb.patch_w);
+  tx = static_cast<int>(px * 8 + (i & 7));
+  ty = static_cast<int>(static_cast<uint32_t>(cb.row_offset) / xd + py * 8 + (i >> 3));
+}
 
 __device__ __forceinline__ const float4 *tile_ptr(const CbView &cb, int64_t g, int q, int lane) {
   return reinterpret_cast<const float4 *>(cb.tiles) + ((g * cb.d4 + q) * WAVE + lane);
@@ -134,7 +160,7 @@ __global__ void k_rows_to_tiles(const float *__restrict__ rows, CbView cb) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       int i = q * 4 + j;
-      v[j] = (row < cb.n && i < cb.d) ? rows[row * cb.d + i] : 0.0f;
+      v[j] = (row < cb.n && i < cb.d) ? rows[(static_cast<int64_t>(unit_of_row(cb, row)) - cb.row_offset) * cb.d + i] : 0.0f;
     }
     *tile_ptr_w(cb, g, q, lane) = make_float4(v[0], v[1], v[2], v[3]);
   }
@@ -150,7 +176,7 @@ __global__ void k_tiles_to_rows(float *__restrict__ rows, CbView cb) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       int i = q * 4 + j;
-      if (i < cb.d) rows[row * cb.d + i] = a[j];
+      if (i < cb.d) rows[(static_cast<int64_t>(unit_of_row(cb, row)) - cb.row_offset) * cb.d + i] = a[j];
     }
   }
 }
@@ -248,7 +274,7 @@ __global__ __launch_bounds__(256) void k_scan_exact(CbView cb, const float4 *__r
     for (int r = 0; r < R; r++) {
       int64_t row = (g0 + r) * WAVE + lane;
       bool live = (g0 + r) < cb.ngroups && row < cb.n;
-      uint32_t grow = static_cast<uint32_t>(row + cb.row_offset);
+      uint32_t grow = unit_of_row(cb, row);
       k[r] = live ? make_key(acc[r][s], tie_knn ? ~grow : grow) : KEY_NONE;
     }
 #pragma unroll
@@ -727,7 +753,7 @@ __global__ __launch_bounds__(256) void k_scan_masked(CbView cb, const float *__r
     }
   }
   int64_t row = g * WAVE + lane;
-  uint32_t grow = static_cast<uint32_t>(row + cb.row_offset);
+  uint32_t grow = unit_of_row(cb, row);
   uint64_t k = row < cb.n ? make_key(acc, tie_knn ? ~grow : grow) : KEY_NONE;
   k = wave_min_u64(k);
   if (lane == 0)
@@ -796,10 +822,13 @@ __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
   const int64_t r0 = g * WAVE;
   const int64_t r_last = (r0 + WAVE < cb.n ? r0 + WAVE : cb.n) - 1;
   const int nlive = static_cast<int>(r_last - r0 + 1);
-  const uint32_t gr0 = static_cast<uint32_t>(r0 + cb.row_offset);
-  const int g_ty0 = static_cast<int>(gr0 / xdim);
-  const int g_ty1 = static_cast<int>(static_cast<uint32_t>(r_last + cb.row_offset) / xdim);
-  const int g_tx0 = static_cast<int>(gr0 % xdim);
+  int g_tx0, g_ty0, g_txl, g_ty1;
+  txty_of_row(cb, r0, g_tx0, g_ty0);
+  txty_of_row(cb, r_last, g_txl, g_ty1);
+  // x extent of the group's units: a patch is 8 wide; a linear group inside one map row spans
+  // [first, last]; one that wraps covers everything
+  const int g_tx1 = cb.patch_w ? g_tx0 + 7 : (g_ty0 == g_ty1 ? g_txl : static_cast<int>(xdim) - 1);
+  const int g_txa = cb.patch_w ? g_tx0 : (g_ty0 == g_ty1 ? g_tx0 : 0);
   const bool small_map = cb.xdim <= 1024 && g_ty1 < 1024;
   const unsigned long long live_mask = nlive >= 64 ? ~0ull : ((1ull << nlive) - 1);
   MemberEntry *out = ent + g * count;
@@ -812,9 +841,18 @@ __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
     if (b < count) {
       const int2 w = bxy[b];
       const StepScalars s = sc[b];
-      if (w.x >= 0 && w.y + s.reach >= g_ty0 && w.y - s.reach <= g_ty1) {
+      // reach (rows) >= radius/0.866 + 1 also bounds the x extent (unit spacing 1, half-unit shifts)
+      if (w.x >= 0 && w.y + s.reach >= g_ty0 && w.y - s.reach <= g_ty1 &&
+          (GAUSS || (w.x + s.reach >= g_txa && w.x - s.reach <= g_tx1))) {
         if (GAUSS) m = live_mask;
-        else {
+        else if (cb.patch_w) {
+          for (int u = 0; u < 64; u++) {
+            const int tx = g_tx0 + (u & 7), ty = g_ty0 + (u >> 3);
+            const float lsq = small_map ? lattice_sq_small(cb.topol, w.x, w.y, tx, ty)
+                                        : lattice_sq(cb.topol, w.x, w.y, tx, ty);
+            if (lsq <= s.thresh) m |= 1ull << u;
+          }
+        } else {
           int tx = g_tx0, ty = g_ty0;
           for (int u = 0; u < nlive; u++) {
             const float lsq = small_map ? lattice_sq_small(cb.topol, w.x, w.y, tx, ty)
@@ -893,9 +931,8 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
   const int q0 = qblk + wave * QW;
   const bool vec = (cb.d & 3) == 0;
   const MemberEntry *list = ent + g * count;
-  const uint32_t xdim = static_cast<uint32_t>(cb.xdim);
-  const uint32_t grow = static_cast<uint32_t>(g * WAVE + lane + cb.row_offset);
-  const int tx = static_cast<int>(grow % xdim), ty = static_cast<int>(grow / xdim);
+  int tx, ty;
+  txty_of_row(cb, g * WAVE + lane, tx, ty);
 
   float4 c[QW];
 #pragma unroll
@@ -1061,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_som_online_step(CbView cb, const float 
   const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave;
   if (g >= cb.ngroups) return;
   const int64_t row = g * WAVE + lane;
-  const uint32_t grow = static_cast<uint32_t>(row + cb.row_offset);
+  const uint32_t grow = unit_of_row(cb, row);
   const uint32_t xdim = static_cast<uint32_t>(cb.xdim);
   const bool live = row < cb.n;
 
@@ -1078,7 +1115,8 @@ __global__ __launch_bounds__(256) void k_som_online_step(CbView cb, const float 
       }
     }
     if (widx != 0xFFFFFFFFu) {
-      const int tx = static_cast<int>(grow % xdim), ty = static_cast<int>(grow / xdim);
+      int tx, ty;
+      txty_of_row(cb, row, tx, ty);
       const int bx = static_cast<int>(widx % xdim), by = static_cast<int>(widx / xdim);
       const float lsq = lattice_sq(cb.topol, bx, by, tx, ty);
       if (GAUSS) { a = gaussian_alpha(lsq, s.thresh, s.alpha); upd = live; }
@@ -1157,7 +1195,7 @@ __global__ __launch_bounds__(256) void k_rerank(CbView cb, const float *__restri
       const float acc = vec ? online_stream<false, true, false, true, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr)
                             : online_stream<false, true, false, false, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr);
       const bool ok = mine && row < cb.n;
-      const uint64_t k = ok ? make_key(acc, static_cast<uint32_t>(row + cb.row_offset)) : KEY_NONE;
+      const uint64_t k = ok ? make_key(acc, unit_of_row(cb, row)) : KEY_NONE;
       best = k < best ? k : best;
       ngroups_done++;
       nrows_done += __popcll(mask);
@@ -1283,7 +1321,7 @@ __global__ __launch_bounds__(256) void k_rerank_pairs(CbView cb, const float *__
     acc = sq_acc(acc, c.z, xv.z);
     acc = sq_acc(acc, c.w, xv.w);
   }
-  const uint64_t k = make_key(acc, static_cast<uint32_t>(row + cb.row_offset));
+  const uint64_t k = make_key(acc, unit_of_row(cb, row));
   atomicMin(reinterpret_cast<unsigned long long *>(keys + pr.x), static_cast<unsigned long long>(k));
 }
 

@@ -291,6 +291,10 @@ extern "C" int somhip_codebook_create(somhip_engine *e, const float *rows, const
   cb->v.xdim = xdim > 0 ? xdim : 1;
   cb->v.topol = topol;
   cb->v.neigh = neigh;
+  cb->v.patch_w = 0;
+  if (topol >= SOMHIP_TOPOL_HEXA && xdim % 8 == 0 && ydim % 8 == 0 && row_offset % (8 * (int64_t)xdim) == 0 &&
+      n_rows % (8 * (int64_t)xdim) == 0 && !getenv("SOMHIP_LINEAR_ROWS"))
+    cb->v.patch_w = xdim / 8;                     // 8x8-unit row groups (kernels.hpp CbView)
   cb->ydim = ydim;
   cb->n_global = n_global;
   size_t tile_bytes = (size_t)cb->v.ngroups * cb->v.d4 * WAVE * 4 * sizeof(float);
