@@ -1088,15 +1088,19 @@ __device__ __forceinline__ float online_stream(const CbView &cb, int64_t g, int 
 template <bool GAUSS, bool MASKED, int U>
 __global__ __launch_bounds__(256) void k_som_online_step(CbView cb, const float *__restrict__ rows,
                                                          const uint8_t *__restrict__ mask,
-                                                         int64_t prev_row, int64_t cur_row,
+                                                         const int64_t *__restrict__ prev_row_p,
+                                                         const int64_t *__restrict__ cur_row_p,
                                                          int has_prev, int has_cur,
                                                          const uint64_t *__restrict__ prev_slot,
                                                          uint64_t *__restrict__ cur_slot,
                                                          const StepScalars *__restrict__ prev_sc,
                                                          const StepScalars *__restrict__ cur_sc) {
+  // every per-iteration quantity arrives through device arrays, so one captured launch
+  // sequence (hipGraph) can be replayed for every chunk of the run
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave;
   if (g >= cb.ngroups) return;
+  const int64_t prev_row = *prev_row_p, cur_row = *cur_row_p;
   const int64_t row = g * WAVE + lane;
   const uint32_t grow = unit_of_row(cb, row);
   const uint32_t xdim = static_cast<uint32_t>(cb.xdim);

@@ -75,6 +75,18 @@ static const char *kKernelNames[KID_COUNT] = {
 extern "C" int somhip_kernel_count(void) { return KID_COUNT; }
 extern "C" const char *somhip_kernel_name(int i) { return (i >= 0 && i < KID_COUNT) ? kKernelNames[i] : ""; }
 
+constexpr int64_t ONLINE_CHUNK = 1024;   // iterations per captured graph
+
+struct OnlineGraphKey {
+  const void *tiles; int64_t n; int d; int patch_w; int64_t row_offset; int xdim; int topol;
+  const void *rows; const void *mask; const void *slot; const void *sc; const void *rowidx; bool G, M;
+  bool operator==(const OnlineGraphKey &o) const {
+    return tiles == o.tiles && n == o.n && d == o.d && patch_w == o.patch_w && row_offset == o.row_offset &&
+           xdim == o.xdim && topol == o.topol && rows == o.rows && mask == o.mask && slot == o.slot && sc == o.sc &&
+           rowidx == o.rowidx && G == o.G && M == o.M;
+  }
+};
+
 struct somhip_engine {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -83,6 +95,13 @@ struct somhip_engine {
   double tau_scale = 1.0;                    // >= 1: widen the pre-filter window (experiments only)
   unsigned long long *d_stats = nullptr;     // [4] re-rank statistics (device)
   uint64_t samples_searched = 0;
+  // ring of pinned host staging buffers for per-batch scalars (H2D without a host sync)
+  void *pin_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t pin_bytes[4] = {0, 0, 0, 0};
+  hipEvent_t pin_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int pin_next = 0;
+  hipGraphExec_t online_graph_exec = nullptr;   // one chunk of k_som_online_step launches
+  OnlineGraphKey online_graph_key{};
   struct Pending { int kid; hipEvent_t a, b; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> pool;
@@ -103,6 +122,29 @@ static int engine_scratch(somhip_engine *e, int slot, size_t bytes, void **out) 
     e->scratch_bytes[slot] = want;
   }
   *out = e->scratch[slot];
+  return 0;
+}
+
+// next pinned staging buffer of the ring (waits only if its previous copy is still in flight)
+static int pin_acquire(somhip_engine *e, size_t bytes, void **host, int *slot) {
+  int i = e->pin_next;
+  e->pin_next = (i + 1) & 3;
+  if (!e->pin_ev[i]) HIPCHK(hipEventCreateWithFlags(&e->pin_ev[i], hipEventDisableTiming));
+  else HIPCHK(hipEventSynchronize(e->pin_ev[i]));
+  if (e->pin_bytes[i] < bytes) {
+    if (e->pin_buf[i]) HIPCHK(hipHostFree(e->pin_buf[i]));
+    e->pin_buf[i] = nullptr; e->pin_bytes[i] = 0;
+    size_t want = std::max(bytes, (size_t)65536);
+    HIPCHK(hipHostMalloc(&e->pin_buf[i], want, hipHostMallocDefault));
+    e->pin_bytes[i] = want;
+  }
+  *host = e->pin_buf[i];
+  *slot = i;
+  return 0;
+}
+static int pin_upload(somhip_engine *e, int slot, void *dev, size_t bytes) {
+  HIPCHK(hipMemcpyAsync(dev, e->pin_buf[slot], bytes, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipEventRecord(e->pin_ev[slot], e->stream));
   return 0;
 }
 
@@ -171,6 +213,11 @@ extern "C" void somhip_engine_destroy(somhip_engine *e) {
   for (auto ev : e->pool) (void)hipEventDestroy(ev);
   for (int i = 0; i < 12; i++) if (e->scratch[i]) (void)hipFree(e->scratch[i]);
   if (e->d_stats) (void)hipFree(e->d_stats);
+  if (e->online_graph_exec) (void)hipGraphExecDestroy(e->online_graph_exec);
+  for (int i = 0; i < 4; i++) {
+    if (e->pin_buf[i]) (void)hipHostFree(e->pin_buf[i]);
+    if (e->pin_ev[i]) (void)hipEventDestroy(e->pin_ev[i]);
+  }
   (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -697,7 +744,7 @@ static int som_scalars(const somhip_codebook *cb, const somhip_dataset *ds, cons
 constexpr int ONLINE_U = 8;    // chunks (KiB) per register buffer; two buffers per wave
 template <bool G, bool M>
 static void launch_online(somhip_engine *e, const somhip_codebook *cb, const somhip_dataset *ds,
-                          int64_t prev_row, int64_t cur_row, int has_prev, int has_cur,
+                          const int64_t *prev_row, const int64_t *cur_row, int has_prev, int has_cur,
                           const uint64_t *prev_slot, uint64_t *cur_slot, const StepScalars *prev_sc,
                           const StepScalars *cur_sc) {
   LaunchTimer t(e, KID_SOM_ONLINE_STEP);
@@ -705,38 +752,77 @@ static void launch_online(somhip_engine *e, const somhip_codebook *cb, const som
                      e->stream, cb->v, ds->d_rows, (const uint8_t *)ds->d_mask, prev_row, cur_row,
                      has_prev, has_cur, prev_slot, cur_slot, prev_sc, cur_sc);
 }
+static void launch_online_any(somhip_engine *e, const somhip_codebook *cb, const somhip_dataset *ds, bool G, bool M,
+                              const int64_t *prev_row, const int64_t *cur_row, int has_prev, int has_cur,
+                              const uint64_t *prev_slot, uint64_t *cur_slot, const StepScalars *prev_sc,
+                              const StepScalars *cur_sc) {
+#define GO(GG, MM) launch_online<GG, MM>(e, cb, ds, prev_row, cur_row, has_prev, has_cur, prev_slot, cur_slot, prev_sc, cur_sc)
+  if (G && M) GO(true, true); else if (G) GO(true, false); else if (M) GO(false, true); else GO(false, false);
+#undef GO
+}
 
+// The online algorithm is one small launch per iteration; a full chunk of them is captured
+// once into a hipGraph (all per-iteration inputs live in device arrays the host refreshes) and
+// replayed, which removes the per-launch host cost that bounds small maps.
 static int som_train_online(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
                             int32_t *trace_index, float *trace_diff) {
   somhip_engine *e = cb->e;
-  const int64_t CH = 4096;
+  const int64_t CH = ONLINE_CHUNK;
   const bool G = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN, M = ds->d_mask != nullptr;
-  void *dslot, *dsc;
-  // entry 0 of both arrays carries the last iteration of the previous chunk
+  void *dslot, *dsc, *drow;
+  // entry 0 of the arrays carries the last iteration of the previous chunk
   CHK(engine_scratch(e, 3, sizeof(uint64_t) * (size_t)(CH + 1), &dslot));
   CHK(engine_scratch(e, 4, sizeof(StepScalars) * (size_t)(CH + 1), &dsc));
+  CHK(engine_scratch(e, 2, sizeof(int64_t) * (size_t)(CH + 1), &drow));
   uint64_t *slot = (uint64_t *)dslot;
   StepScalars *sc = (StepScalars *)dsc;
+  int64_t *rowidx = (int64_t *)drow;
   std::vector<StepScalars> hsc((size_t)CH + 1);
   std::vector<uint64_t> hslot((size_t)CH + 1);
-  int64_t prev_row = 0;
+  std::vector<int64_t> hrow((size_t)CH + 1);
+  // entry 0 before the first iteration: "teaches nothing" (reach < 0), so has_prev can always be 1
+  hsc[0].alpha = 0.f; hsc[0].thresh = -1.f; hsc[0].fixed = -1; hsc[0].reach = -1;
+  hrow[0] = 0;
+  HIPCHK(hipMemcpyAsync(sc, hsc.data(), sizeof(StepScalars), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(rowidx, hrow.data(), sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemsetAsync(slot, 0xFF, sizeof(uint64_t), e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+
+  // graph of one full chunk, cached per engine while its arguments stay the same
+  OnlineGraphKey key{cb->v.tiles, cb->v.n, cb->v.d, cb->v.patch_w, cb->v.row_offset, cb->v.xdim, cb->v.topol,
+                     ds->d_rows, ds->d_mask, slot, sc, rowidx, G, M};
+  const bool want_graph = !e->timing && p->count >= CH && !getenv("SOMHIP_NO_GRAPH");
+  if (want_graph && !(e->online_graph_exec && e->online_graph_key == key)) {
+    if (e->online_graph_exec) { (void)hipGraphExecDestroy(e->online_graph_exec); e->online_graph_exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    for (int64_t j = 0; j < CH; j++)
+      launch_online_any(e, cb, ds, G, M, rowidx + j, rowidx + j + 1, 1, 1, slot + j, slot + j + 1, sc + j, sc + j + 1);
+    HIPCHK(hipStreamEndCapture(e->stream, &graph));
+    HIPCHK(hipGraphInstantiate(&e->online_graph_exec, graph, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(graph));
+    e->online_graph_key = key;
+  }
+
   bool have_prev = false;
+  int64_t last_row = 0;
   for (int64_t off = 0; off < p->count; off += CH) {
     int64_t c = std::min(CH, p->count - off);
     int64_t it0 = p->start_iter + off, row0 = (p->data_first + off) % ds->n;
     CHK(som_scalars(cb, ds, p, it0, c, row0, hsc.data() + 1));
+    for (int64_t j = 0; j < c; j++) hrow[(size_t)j + 1] = (row0 + j) % ds->n;
     HIPCHK(hipMemcpyAsync(sc + 1, hsc.data() + 1, sizeof(StepScalars) * (size_t)c, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(rowidx + 1, hrow.data() + 1, sizeof(int64_t) * (size_t)c, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemsetAsync(slot + 1, 0xFF, sizeof(uint64_t) * (size_t)c, e->stream));
-    for (int64_t j = 0; j < c; j++) {
-      int64_t cur_row = (row0 + j) % ds->n;
-      int hp = have_prev ? 1 : 0;
-#define GO(GG, MM) launch_online<GG, MM>(e, cb, ds, prev_row, cur_row, hp, 1, slot + j, slot + j + 1, sc + j, sc + j + 1)
-      if (G && M) GO(true, true); else if (G) GO(true, false); else if (M) GO(false, true); else GO(false, false);
-#undef GO
-      prev_row = cur_row;
-      have_prev = true;
+    if (want_graph && c == CH) {
+      HIPCHK(hipGraphLaunch(e->online_graph_exec, e->stream));
+    } else {
+      for (int64_t j = 0; j < c; j++)
+        launch_online_any(e, cb, ds, G, M, rowidx + j, rowidx + j + 1, 1, 1, slot + j, slot + j + 1, sc + j, sc + j + 1);
     }
     HIPCHK(hipGetLastError());
+    have_prev = true;
+    last_row = hrow[(size_t)c];
     if (trace_index || trace_diff) {
       HIPCHK(hipMemcpyAsync(hslot.data(), slot + 1, sizeof(uint64_t) * (size_t)c, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
@@ -750,16 +836,16 @@ static int som_train_online(somhip_codebook *cb, somhip_dataset *ds, const somhi
         if (trace_diff) trace_diff[off + j] = df;
       }
     }
-    // carry the last iteration's slot + scalars into entry 0 for the next chunk / the flush
+    // carry the last iteration's slot + scalars + row into entry 0 for the next chunk / the flush
     HIPCHK(hipMemcpyAsync(slot, slot + c, sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(sc, sc + c, sizeof(StepScalars), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(rowidx, rowidx + c, sizeof(int64_t), hipMemcpyDeviceToDevice, e->stream));
     // the host staging vectors are reused by the next chunk
     HIPCHK(hipStreamSynchronize(e->stream));
   }
+  (void)last_row;
   if (have_prev) {   // flush: apply the last iteration's update
-#define GO(GG, MM) launch_online<GG, MM>(e, cb, ds, prev_row, prev_row, 1, 0, slot, slot, sc, sc)
-    if (G && M) GO(true, true); else if (G) GO(true, false); else if (M) GO(false, true); else GO(false, false);
-#undef GO
+    launch_online_any(e, cb, ds, G, M, rowidx, rowidx, 1, 0, slot, slot, sc, sc);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -815,13 +901,13 @@ extern "C" int somhip_som_batch_update(somhip_codebook *cb, somhip_dataset *ds,
   if (count <= 0) return 0;
   somhip_engine *e = cb->e;
   HIPCHK(hipSetDevice(e->device));
-  std::vector<StepScalars> hsc((size_t)count);
-  CHK(som_scalars(cb, ds, p, batch_start_iter, count, data_first % ds->n, hsc.data()));
-  void *dsc;
+  void *dsc, *hsc;
+  int slot;
   CHK(engine_scratch(e, 4, sizeof(StepScalars) * (size_t)count, &dsc));
-  HIPCHK(hipMemcpyAsync(dsc, hsc.data(), sizeof(StepScalars) * (size_t)count, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));   // hsc goes out of scope
-  return som_update_run(cb, ds, data_first % ds->n, count, dev_keys, (const StepScalars *)dsc);
+  CHK(pin_acquire(e, sizeof(StepScalars) * (size_t)count, &hsc, &slot));
+  CHK(som_scalars(cb, ds, p, batch_start_iter, count, data_first % ds->n, (StepScalars *)hsc));
+  CHK(pin_upload(e, slot, dsc, sizeof(StepScalars) * (size_t)count));
+  return som_update_run(cb, ds, data_first % ds->n, count, dev_keys, (const StepScalars *)dsc);   // asynchronous
 }
 
 static int som_train_batched(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
@@ -831,26 +917,29 @@ static int som_train_batched(somhip_codebook *cb, somhip_dataset *ds, const somh
   void *dkeys, *dsc;
   CHK(engine_scratch(e, 3, sizeof(uint64_t) * (size_t)B, &dkeys));
   CHK(engine_scratch(e, 4, sizeof(StepScalars) * (size_t)B, &dsc));
-  std::vector<StepScalars> hsc((size_t)B);
   std::vector<uint64_t> hk((size_t)B);
-  // batches are aligned to the schedule (iteration 0, B, 2B, ...), as in the oracle
+  const bool trace = trace_index || trace_diff;
+  // batches are aligned to the schedule (iteration 0, B, 2B, ...), as in the oracle; the host runs
+  // ahead of the GPU (scalars go through a ring of pinned buffers) unless a trace is wanted
   for (int64_t off = 0; off < p->count;) {
     int64_t it0 = p->start_iter + off;
     int64_t c = std::min(B - (it0 % B), p->count - off);
     int64_t row0 = (p->data_first + off) % ds->n;
-    CHK(som_scalars(cb, ds, p, it0, c, row0, hsc.data()));
-    HIPCHK(hipMemcpyAsync(dsc, hsc.data(), sizeof(StepScalars) * (size_t)c, hipMemcpyHostToDevice, e->stream));
+    void *hscv;
+    int slot;
+    CHK(pin_acquire(e, sizeof(StepScalars) * (size_t)c, &hscv, &slot));
+    StepScalars *hsc = (StepScalars *)hscv;
+    CHK(som_scalars(cb, ds, p, it0, c, row0, hsc));
+    CHK(pin_upload(e, slot, dsc, sizeof(StepScalars) * (size_t)c));
     CHK(scan_keys_top1(cb, ds, row0, c, (uint64_t *)dkeys));
     CHK(som_update_run(cb, ds, row0, c, (const uint64_t *)dkeys, (const StepScalars *)dsc));
-    if (trace_index || trace_diff) {
+    if (trace) {
       HIPCHK(hipMemcpyAsync(hk.data(), dkeys, sizeof(uint64_t) * (size_t)c, hipMemcpyDeviceToHost, e->stream));
-    }
-    HIPCHK(hipStreamSynchronize(e->stream));
-    if (trace_index || trace_diff) {
+      HIPCHK(hipStreamSynchronize(e->stream));
       for (int64_t j = 0; j < c; j++) {
         int32_t idx; float df;
-        if (hsc[(size_t)j].fixed >= 0) { idx = -3; df = -1.0f; }
-        else if (hsc[(size_t)j].reach < 0) { idx = -2; df = -1.0f; }
+        if (hsc[j].fixed >= 0) { idx = -3; df = -1.0f; }
+        else if (hsc[j].reach < 0) { idx = -2; df = -1.0f; }
         else decode_key(hk[(size_t)j], false, &idx, &df);
         if (trace_index) trace_index[off + j] = idx;
         if (trace_diff) trace_diff[off + j] = df;
@@ -858,6 +947,7 @@ static int som_train_batched(somhip_codebook *cb, somhip_dataset *ds, const somh
     }
     off += c;
   }
+  HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
 }
 

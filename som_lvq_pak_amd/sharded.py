@@ -63,7 +63,8 @@ class ShardedSom:
     `shard` provides:
         winner_keys(first, count) -> int64 torch tensor [count] of this shard's packed keys
         update(it0, count, first, keys)  apply iterations [it0, it0+count) to the local rows
-        sync()                           make the shard's device work visible to torch
+        collective_scope()               context in which torch collectives are ordered after
+                                         winner_keys and before update (same stream, or host syncs)
     """
 
     def __init__(self, shard, batch, n_data):
@@ -73,9 +74,8 @@ class ShardedSom:
 
     def step(self, it0, data_first, count):
         keys = self.shard.winner_keys(data_first, count)
-        self.shard.sync()
-        allreduce_min_keys(keys)
-        self.shard.sync_torch()
+        with self.shard.collective_scope():
+            allreduce_min_keys(keys)
         self.shard.update(it0, count, data_first, keys)
         return keys
 
@@ -118,9 +118,21 @@ class GpuShard:
         check(self.e.lib.somhip_som_batch_update(self.cb.h, self.ds.h, C.byref(p), it0, count, first,
                                                  C.c_void_p(keys.data_ptr())))
 
-    def sync(self):
-        self.e.sync()
-
-    def sync_torch(self):
+    def collective_scope(self):
+        """RCCL: enqueue the collective on the engine's own HIP stream (torch.cuda.ExternalStream), so
+        scan -> all-reduce -> update are stream-ordered with no host synchronisation.  gloo
+        rehearsal (host-staged): plain host syncs around it."""
+        import contextlib
         import torch
-        torch.cuda.current_stream().synchronize()
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_backend() == "nccl":
+            if not hasattr(self, "_ext"):
+                self._ext = torch.cuda.ExternalStream(self.e.stream, device=torch.device("cuda", self.e.device))
+            return torch.cuda.stream(self._ext)
+
+        @contextlib.contextmanager
+        def host_synced():
+            self.e.sync()
+            yield
+            torch.cuda.current_stream().synchronize()
+        return host_synced()

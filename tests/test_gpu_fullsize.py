@@ -129,3 +129,42 @@ def test_c4_online_equals_minibatch_of_one_and_reduced_oracle(world, oracle):
     ti, td = E.som_train(cbs, dss, 600, 0.05, 20.0, batch=128)
     assert np.array_equal(ti, oi) and np.array_equal(bits(td), bits(od))
     assert np.array_equal(bits(cbs.download()), bits(oc))
+
+
+def test_rccl_stream_ordered_step_single_rank(oracle):
+    """The production multi-GPU step (scan -> RCCL all-reduce on the engine's own stream via
+    torch.cuda.ExternalStream -> update, no host sync) exercised with a 1-rank NCCL group in a
+    child process: must equal the plain mini-batch run."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import os, sys, ctypes as C
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from conftest import synth
+from oracle import Oracle
+from som_lvq_pak_amd import engine as E, sharded
+from som_lvq_pak_amd._lib import SomParams
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+orc = Oracle()
+x, _ = synth(5, 900, 24)
+ini = orc.randinit(x, 16, 16, 3)
+want, wi, _ = orc.som_train(ini, 16, 16, 3, 1, x, 1536, 0.05, 6.0, batch=256)
+eng = E.Engine(0)
+ds = E.Dataset(eng, x)
+cb = E.Codebook(eng, ini, 3, 1, 16, 16)
+sh = sharded.GpuShard(eng, cb, ds, lambda: SomParams(1536, 0.05, 6.0, 1, 0, 0, 256, 0, 0, 0), 256)
+som = sharded.ShardedSom(sh, 256, 900)
+winners = som.train(1536)
+eng.sync(); torch.cuda.synchronize()
+idx = np.concatenate([sharded.unpack_keys(w.cpu().numpy())[1] for w in winners])
+ok = np.array_equal(idx, wi) and np.array_equal(cb.download().view(np.uint32), want.view(np.uint32))
+dist.destroy_process_group()
+print("RESULT", ok)
+''' % (ROOT, ROOT)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert "RESULT True" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
