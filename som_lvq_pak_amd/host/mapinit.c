@@ -1,0 +1,80 @@
+/* mapinit / randinit -- random initialization of a map codebook in the bounding box of the
+ * data (SOM_PAK mapinit.c:53-182 driving randinit_codes som_rout.c:34-162).  Host-only: this
+ * is the step before the hot path.  `lininit` (principal-axes initialization) is not part of
+ * this engine; the name is recognised and refused. */
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include "pak.h"
+
+static const char *usage =
+    "randinit (mapinit -init rand) - random initialization of a SOM codebook\n"
+    "Required:  -din file  -cout file  -topol hexa|rect  -neigh bubble|gaussian  -xdim N  -ydim N\n"
+    "Optional:  -rand seed  -init rand  -v level\n";
+
+int main(int argc, char **argv)
+{
+  global_options(argc, argv);
+  if (extract_parameter(argc, argv, "-help", OPTION2)) { fputs(usage, stdout); exit(0); }
+  const char *progname = pak_progname(argv[0]);
+  int init_rand = strcasecmp(progname, "randinit") == 0, init_lin = strcasecmp(progname, "lininit") == 0;
+  char *in_data_file = extract_parameter(argc, argv, "-din", ALWAYS);
+  char *out_code_file = extract_parameter(argc, argv, "-cout", ALWAYS);
+  long randomize = (int)oatoi(extract_parameter(argc, argv, "-rand", OPTION), 0);
+  char *s = extract_parameter(argc, argv, "-topol", ALWAYS);
+  int topol = !strcasecmp(s, "hexa") ? TOPOL_HEXA : !strcasecmp(s, "rect") ? TOPOL_RECT : TOPOL_UNKNOWN;
+  if (topol == TOPOL_UNKNOWN) { fprintf(stderr, "Unknown topology type %s\n", s); exit(1); }
+  s = extract_parameter(argc, argv, "-neigh", ALWAYS);
+  int neigh = !strcasecmp(s, "bubble") ? NEIGH_BUBBLE : !strcasecmp(s, "gaussian") ? NEIGH_GAUSSIAN : NEIGH_UNKNOWN;
+  if (neigh == NEIGH_UNKNOWN) { fprintf(stderr, "Unknown neighborhood type %s\n", s); exit(1); }
+  int xdim = (int)oatoi(extract_parameter(argc, argv, "-xdim", ALWAYS), 0);
+  int ydim = (int)oatoi(extract_parameter(argc, argv, "-ydim", ALWAYS), 0);
+  s = extract_parameter(argc, argv, "-init", OPTION);
+  if (s) { init_lin = strcmp(s, "lin") == 0; init_rand = strcmp(s, "rand") == 0; }
+  if (init_lin) { fprintf(stderr, "lininit is not provided by this engine; use randinit\n"); exit(1); }
+  if (!init_rand) { fprintf(stderr, "Unknown initialization type %s\n", s ? s : progname); exit(1); }
+  long noc = (long)xdim * ydim;
+  if (noc <= 0 || xdim < 0) { fprintf(stderr, "Dimensions of map (%d %d) are incorrect\n", xdim, ydim); exit(1); }
+
+  ifverbose(2) fprintf(stderr, "Input entries are read from file %s\n", in_data_file);
+  struct entries *data = open_entries(in_data_file, 0, 1);
+  if (!data) { fprintf(stderr, "Can't open data file '%s'\n", in_data_file); exit(1); }
+  init_random((int)randomize);
+  int dim = data->dimension;
+
+  /* bounding box over unmasked components; the reference seeds its maximum with FLT_MIN
+   * (the smallest positive float), som_rout.c:108-111 */
+  float *hi = malloc(sizeof(float) * dim), *lo = malloc(sizeof(float) * dim);
+  long *cnt = calloc(dim, sizeof(long));
+  for (int i = 0; i < dim; i++) { hi[i] = FLT_MIN; lo[i] = FLT_MAX; }
+  for (long r = 0; r < data->num_entries; r++) {
+    struct data_entry *e = &data->rows[r];
+    for (int i = 0; i < dim; i++)
+      if (!(e->mask && e->mask[i])) {
+        cnt[i]++;
+        if (hi[i] < e->points[i]) hi[i] = e->points[i];
+        if (lo[i] > e->points[i]) lo[i] = e->points[i];
+      }
+  }
+  for (int i = 0; i < dim; i++)
+    if (cnt[i] == 0) fprintf(stderr, "randinit_codes: warning! component %d has no data, using 0.0\n", i + 1);
+
+  struct entries *codes = calloc(1, sizeof *codes);
+  codes->dimension = (short)dim; codes->topol = (short)topol; codes->neigh = (short)neigh;
+  codes->xdim = (short)xdim; codes->ydim = (short)ydim; codes->num_entries = noc;
+  codes->points = malloc(sizeof(float) * noc * dim);
+  codes->rows = calloc(noc, sizeof(struct data_entry));
+  for (long k = 0; k < noc; k++) {
+    codes->rows[k].points = codes->points + k * dim;
+    for (int i = 0; i < dim; i++)                  /* som_rout.c:140-150 */
+      codes->rows[k].points[i] = cnt[i] > 0 ? lo[i] + (hi[i] - lo[i]) * ((float)orand() / 32768.0) : 0.0;
+  }
+  ifverbose(2) fprintf(stderr, "Codebook entries are saved to file %s\n", out_code_file);
+  char comments[256];
+  snprintf(comments, sizeof comments, "# random seed: %ld\n", randomize);
+  save_entries_wcomments(codes, out_code_file, comments);
+  close_entries(data); close_entries(codes);
+  free(hi); free(lo); free(cnt);
+  return 0;
+}

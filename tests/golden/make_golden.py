@@ -101,6 +101,9 @@ def main():
     shutil.copyfile(os.path.join(CLI, "somexample.cod"), os.path.join(CLI, "somexample_vcal.cod"))
     run("vcal", "-din", d("ex_fts.dat"), "-cin", "somexample.cod", "-cout", "somexample_vcal.cod")
     exp["som"]["somexample_vcal_md5"] = md5(os.path.join(CLI, "somexample_vcal.cod"))
+    run("visual", "-din", d("ex_fts.dat"), "-cin", "somexample_vcal.cod", "-dout", "somexample_fts.vis")
+    exp["som"]["somexample_vis_md5"] = md5(os.path.join(CLI, "somexample_fts.vis"))
+    exp["som"]["randinit_md5"] = md5(os.path.join(CLI, "som_init_hexa_bubble.cod"))
 
     # ---------------- LVQ chains ----------------
     run("eveninit", "-din", d("ex1.dat"), "-cout", "lvq_init.cod", "-noc", 200)

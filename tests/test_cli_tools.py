@@ -157,3 +157,32 @@ def test_vsom_minibatch_flag(tools, tmp_path, oracle, exdata):
     run("vsom", "-din", os.path.join(DATA, "ex.dat"), "-cin", os.path.join(CLI, "som_init_hexa_bubble.cod"),
         "-cout", out, "-rlen", 5000, "-alpha", 0.05, "-radius", 10, "-batch", 64, "-v", 0)
     assert md5(out) == md5(ref)
+
+
+def test_randinit_matches_reference(tools, tmp_path):
+    """host-only step before the path: same LCG, same bounding-box rule, same bytes"""
+    out = tmp_path / "init.cod"
+    run("randinit", "-din", os.path.join(DATA, "ex.dat"), "-cout", out, "-xdim", 12, "-ydim", 8,
+        "-topol", "hexa", "-neigh", "bubble", "-rand", 123, "-v", 0)
+    assert md5(out) == EXPECTED["som"]["randinit_md5"]
+    p = run("lininit", "-din", os.path.join(DATA, "ex.dat"), "-cout", out, "-xdim", 12, "-ydim", 8,
+            "-topol", "hexa", "-neigh", "bubble", check=False)
+    assert p.returncode == 1 and "lininit is not provided" in p.stderr
+
+
+@pytest.mark.gpu
+def test_whole_somexample_on_these_tools(tools, tmp_path):
+    """reference Makefile:195-205 end to end with these binaries only:
+    randinit -> vsom -> vsom -> qerror -> vcal -> visual"""
+    d = os.path.join(DATA, "ex.dat")
+    cod = tmp_path / "ex.cod"
+    run("randinit", "-din", d, "-cout", cod, "-xdim", 12, "-ydim", 8, "-topol", "hexa", "-neigh", "bubble",
+        "-rand", 123, "-v", 0)
+    run("vsom", "-din", d, "-cin", cod, "-cout", cod, "-rlen", 1000, "-alpha", 0.05, "-radius", 10, "-v", 0)
+    run("vsom", "-din", d, "-cin", cod, "-cout", cod, "-rlen", 10000, "-alpha", 0.02, "-radius", 3, "-v", 0)
+    assert run("qerror", "-din", d, "-cin", cod, "-v", 0).stdout == "3.571006\n"
+    run("vcal", "-din", os.path.join(DATA, "ex_fts.dat"), "-cin", cod, "-cout", cod, "-v", 0)
+    assert md5(cod) == EXPECTED["som"]["somexample_vcal_md5"]
+    vis = tmp_path / "ex.vis"
+    run("visual", "-din", os.path.join(DATA, "ex_fts.dat"), "-cin", cod, "-dout", vis, "-v", 0)
+    assert md5(vis) == EXPECTED["som"]["somexample_vis_md5"]
