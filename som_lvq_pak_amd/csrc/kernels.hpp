@@ -1346,10 +1346,14 @@ struct LvqStep {
   int32_t label;       // the sample's first label
 };
 
-__device__ __forceinline__ void top2_insert(uint64_t &k0, uint64_t &k1, uint64_t v) {
-  if (v < k0) { k1 = k0; k0 = v; }
-  else if (v < k1) k1 = v;
-}
+// insert v into the running two smallest (k0 <= k1), branch-free and by value
+#define TOP2_INSERT(k0, k1, v)                         \
+  do {                                                 \
+    const uint64_t v_ = (v);                           \
+    const uint64_t hi_ = v_ > (k0) ? v_ : (k0);        \
+    (k0) = v_ < (k0) ? v_ : (k0);                      \
+    (k1) = hi_ < (k1) ? hi_ : (k1);                    \
+  } while (0)
 
 __global__ __launch_bounds__(256) void k_lvq_online_step(CbView cb, const float *__restrict__ rows,
                                                          const int32_t *__restrict__ clabels,
@@ -1369,12 +1373,12 @@ __global__ __launch_bounds__(256) void k_lvq_online_step(CbView cb, const float 
   const bool live = g < cb.ngroups && row < cb.n;
 
   // --- merge the previous iteration's partial top-2 (identical in every workgroup) ---
-  int64_t u_row[2] = {-1, -1};
-  float u_a[2] = {0.f, 0.f};
+  int64_t u_row0 = -1, u_row1 = -1;        // the (at most two) rows iteration t-1 corrects
+  float u_a0 = 0.f, u_a1 = 0.f;
   if (has_prev) {
     if (wave == 0) {
       uint64_t k0 = KEY_NONE, k1 = KEY_NONE;
-      for (int j = lane; j < prev_nblk * 2; j += WAVE) top2_insert(k0, k1, prev_part[j]);
+      for (int j = lane; j < prev_nblk * 2; j += WAVE) TOP2_INSERT(k0, k1, prev_part[j]);
       uint64_t b0 = wave_min_u64(k0);
       uint64_t mine = (k0 == b0) ? k1 : k0;
       uint64_t b1 = wave_min_u64(mine);
@@ -1388,12 +1392,12 @@ __global__ __launch_bounds__(256) void k_lvq_online_step(CbView cb, const float 
     const int64_t i0 = knn == 2 ? static_cast<int64_t>(~t0) : static_cast<int64_t>(t0);
     const int64_t i1 = static_cast<int64_t>(~t1);
     if (st.kind == 1) {                                   // LVQ1, lvq_rout.c:552-555
-      u_row[0] = i0;
-      u_a[0] = (clabels[i0] == st.label) ? st.alpha : -st.alpha;
+      u_row0 = i0;
+      u_a0 = (clabels[i0] == st.label) ? st.alpha : -st.alpha;
     } else if (st.kind == 2) {                            // OLVQ1, lvq_rout.c:658-673
-      u_row[0] = i0;
+      u_row0 = i0;
       float ta = talpha[i0];
-      u_a[0] = (clabels[i0] == st.label) ? ta : -ta;
+      u_a0 = (clabels[i0] == st.label) ? ta : -ta;
     } else {                                              // LVQ2.1 / LVQ3
       const int l0 = clabels[i0], l1 = clabels[i1];
       const float d0 = __uint_as_float(static_cast<uint32_t>(b0 >> 32));
@@ -1403,14 +1407,14 @@ __global__ __launch_bounds__(256) void k_lvq_online_step(CbView cb, const float 
           if ((d0 / d1) > st.win_ratio) {                 // lvq_rout.c:770 / :876
             int64_t best = i0, nbest = i1;
             if (l1 == st.label) { best = i1; nbest = i0; }
-            u_row[0] = best;  u_a[0] = st.alpha;
-            u_row[1] = nbest; u_a[1] = -st.alpha;
+            u_row0 = best;  u_a0 = st.alpha;
+            u_row1 = nbest; u_a1 = -st.alpha;
           }
         }
       } else if (st.kind == 4 && l0 == st.label) {        // lvq_rout.c:890-895
         float ae = st.alpha * st.epsilon;
-        u_row[0] = i0; u_a[0] = ae;
-        u_row[1] = i1; u_a[1] = ae;
+        u_row0 = i0; u_a0 = ae;
+        u_row1 = i1; u_a1 = ae;
       }
     }
   }
@@ -1418,46 +1422,23 @@ __global__ __launch_bounds__(256) void k_lvq_online_step(CbView cb, const float 
   // which (if any) correction applies to this lane's row; if both name the same row
   // (cannot happen: two distinct neighbours) the first wins
   int which = -1;
-  if (live) { if (grow == u_row[0]) which = 0; else if (grow == u_row[1]) which = 1; }
+  if (live) { if (grow == u_row0) which = 0; else if (grow == u_row1) which = 1; }
   const bool upd = which >= 0;
-  const float a = which == 1 ? u_a[1] : u_a[0];
+  const float a = which == 1 ? u_a1 : u_a0;
   const bool any_upd = __any(upd);
   const float *xp = rows + prev_row * cb.d;
   const float *xc = rows + cur_row * cb.d;
   const bool vec = (cb.d & 3) == 0;
   float acc = 0.0f;
   if (g < cb.ngroups && (any_upd || has_cur)) {
-    for (int q = 0; q < cb.d4; q++) {
-      float4 c = *tile_ptr(cb, g, q, lane);
-      if (any_upd) {
-        float4 x;
-        if (vec) x = reinterpret_cast<const float4 *>(xp)[q];
-        else {
-          x.x = q * 4 + 0 < cb.d ? xp[q * 4 + 0] : 0.f;
-          x.y = q * 4 + 1 < cb.d ? xp[q * 4 + 1] : 0.f;
-          x.z = q * 4 + 2 < cb.d ? xp[q * 4 + 2] : 0.f;
-          x.w = q * 4 + 3 < cb.d ? xp[q * 4 + 3] : 0.f;
-        }
-        if (upd) {
-          c = adapt4(c, x, a);
-          *tile_ptr_w(cb, g, q, lane) = c;
-        }
-      }
-      if (has_cur) {
-        float4 x;
-        if (vec) x = reinterpret_cast<const float4 *>(xc)[q];
-        else {
-          x.x = q * 4 + 0 < cb.d ? xc[q * 4 + 0] : 0.f;
-          x.y = q * 4 + 1 < cb.d ? xc[q * 4 + 1] : 0.f;
-          x.z = q * 4 + 2 < cb.d ? xc[q * 4 + 2] : 0.f;
-          x.w = q * 4 + 3 < cb.d ? xc[q * 4 + 3] : 0.f;
-        }
-        acc = sq_acc(acc, c.x, x.x);
-        acc = sq_acc(acc, c.y, x.y);
-        acc = sq_acc(acc, c.z, x.z);
-        acc = sq_acc(acc, c.w, x.w);
-      }
-    }
+    // same pipelined, branch-free row stream as the SOM step (two register buffers per wave)
+#define LVQ_GO(UU, SS)                                                                                  \
+    acc = vec ? online_stream<UU, SS, false, true, 8>(cb, g, lane, upd, a, xp, xc, nullptr, nullptr)     \
+              : online_stream<UU, SS, false, false, 8>(cb, g, lane, upd, a, xp, xc, nullptr, nullptr)
+    if (any_upd && has_cur) { LVQ_GO(true, true); }
+    else if (has_cur) { LVQ_GO(false, true); }
+    else { LVQ_GO(true, false); }
+#undef LVQ_GO
   }
   // OLVQ1: the owner of the corrected row advances its rate (lvq_rout.c:663, :670-672)
   if (has_prev && upd && which == 0) {
@@ -1483,7 +1464,7 @@ __global__ __launch_bounds__(256) void k_lvq_online_step(CbView cb, const float 
     __syncthreads();
     if (threadIdx.x == 0) {
       uint64_t k0 = KEY_NONE, k1 = KEY_NONE;
-      for (int w = 0; w < 4; w++) { top2_insert(k0, k1, sh[w][0]); top2_insert(k0, k1, sh[w][1]); }
+      for (int w = 0; w < 4; w++) { TOP2_INSERT(k0, k1, sh[w][0]); TOP2_INSERT(k0, k1, sh[w][1]); }
       cur_part[blockIdx.x * 2 + 0] = k0;
       cur_part[blockIdx.x * 2 + 1] = k1;
     }
