@@ -239,9 +239,24 @@ def main():
                          "unit": "TFLOP/s", "frac": alg / avg_s / 1e12 / PEAK_F32_TFLOPS, "note": note})
             return base
 
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (bench.py cannot run the
+        # profiler on itself); null when the file or the kernel is missing
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        except Exception:
+            pass
+
+        def with_traffic(r):
+            k = pmc.get("kernels", {}).get(r["kernel"])
+            if k and (xdim, ydim, d, world) == (256, 256, 512, 1):
+                r["traffic"] = {"bytes_per_launch": k["bytes"], "read": k["read_bytes"], "write": k["write_bytes"],
+                                "source": "profiles/r01_pmc_traffic.json: " + pmc.get("source", "")}
+            return r
+
         ranked = sorted((k for k in table if table[k][0]), key=lambda k: -table[k][1])
-        roof = roof_of(ranked[0])
-        roof_other = [roof_of(k) for k in ranked[1:3]]
+        roof = with_traffic(roof_of(ranked[0]))
+        roof_other = [with_traffic(roof_of(k)) for k in ranked[1:3]]
         cpu = cpu_baseline(a, init, data, xdim, ydim, d, radius) if (world == 1 and a.cpu_vectors > 0) else None
         out = {
             "metric": "training_vectors_per_sec", "value": value, "unit": "vectors/s",
