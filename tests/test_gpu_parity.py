@@ -393,3 +393,68 @@ def test_prefilter_error_is_inside_its_bound(eng, E, mode, d, offset, scale):
     err = np.abs(wmin.astype(np.float64) + xn[None, :] - direct.astype(np.float64))
     ratio = err / (0.5 * tau.astype(np.float64))[None, :]
     assert ratio.max() < 0.5, ratio.max()            # inside the bound with a factor 2 to spare
+
+
+# --------------------------------------------------------------------------- 8x8-patch row order
+@pytest.mark.parametrize("topol,neigh", [(3, 1), (3, 2), (4, 1), (4, 2)])
+@pytest.mark.parametrize("batch", [1, 48])
+def test_patch_row_order_equals_oracle(eng, E, oracle, topol, neigh, batch):
+    """maps with sides multiple of 8 are stored as 8x8 patches of units; every result must still be
+    in the reference's unit order (trace indices, downloaded rows)"""
+    x, _ = synth(71 + topol + neigh, 800, 12)
+    ini = oracle.randinit(x, 24, 16, 9)
+    oc, oi, od = oracle.som_train(ini, 24, 16, topol, neigh, x, 1200, 0.06, 7.0, batch=batch)
+    cb, ds = E.Codebook(eng, ini, topol, neigh, 24, 16), E.Dataset(eng, x)
+    assert np.array_equal(bits(cb.download()), bits(ini))
+    ti, td = E.som_train(cb, ds, 1200, 0.06, 7.0, batch=batch)
+    assert np.array_equal(ti, oi)
+    assert np.array_equal(bits(td), bits(od))
+    assert np.array_equal(bits(cb.download()), bits(oc))
+    wi, wd, _ = E.find_winners(cb, ds)
+    qi, qd, _ = oracle.winners(oc, x)
+    assert np.array_equal(wi, qi) and np.array_equal(bits(wd), bits(qd))
+
+
+def test_patch_row_order_masks_fixed_weights_and_shards(eng, E, oracle):
+    import ctypes as C
+    from som_lvq_pak_amd._lib import SomParams
+    rs = np.random.RandomState(3)
+    x, _ = synth(81, 500, 10)
+    mask = (rs.rand(500, 10) < 0.1).astype(np.uint8)
+    mask[11] = 1
+    weight = rs.randint(0, 3, size=500).astype(np.int16)
+    fixed = np.full((500, 2), -1, dtype=np.int16)
+    for r in rs.choice(500, 25, replace=False):
+        fixed[r] = (rs.randint(0, 16), rs.randint(0, 16))
+    ini = oracle.randinit(x, 16, 16, 4)
+    for batch in (1, 40):
+        oc, oi, od = oracle.som_train(ini, 16, 16, 3, 1, x, 900, 0.07, 5.0, weight=weight, fixed_xy=fixed,
+                                      mask=mask, fixed_on=1, weights_on=1, batch=batch)
+        cb = E.Codebook(eng, ini, 3, 1, 16, 16)
+        ds = E.Dataset(eng, x, mask=mask, weight=weight, fixed_xy=fixed)
+        ti, td = E.som_train(cb, ds, 900, 0.07, 5.0, use_fixed=1, use_weights=1, batch=batch)
+        assert np.array_equal(ti, oi), batch
+        assert np.array_equal(bits(td), bits(od)), batch
+        assert np.array_equal(bits(cb.download()), bits(oc)), batch
+    # two shards on an 8-row boundary (both in patch order) == the whole map
+    oc, oi, _ = oracle.som_train(ini, 16, 16, 3, 1, x, 512, 0.05, 6.0, batch=64)
+    shards = [E.Codebook(eng, ini[:128], 3, 1, 16, 16, row_offset=0, n_global=256),
+              E.Codebook(eng, ini[128:], 3, 1, 16, 16, row_offset=128, n_global=256)]
+    ds = E.Dataset(eng, x)
+    kb = [eng.device_alloc(8 * 64) for _ in range(3)]
+    hk = [np.empty(64, dtype=np.uint64) for _ in range(2)]
+    p = SomParams(512, 0.05, 6.0, 1, 0, 0, 64, 0, 512, 0)
+    for it0 in range(0, 512, 64):
+        first = it0 % 500
+        for s in range(2):
+            E.check(eng.lib.somhip_batch_winner_keys(shards[s].h, ds.h, first, 64, kb[s]))
+            E.check(eng.lib.somhip_copy_to_host(eng.h, hk[s].ctypes.data_as(C.c_void_p), kb[s], 8 * 64))
+        merged = np.minimum(hk[0], hk[1])
+        E.check(eng.lib.somhip_copy_to_device(eng.h, kb[2], merged.ctypes.data_as(C.c_void_p), 8 * 64))
+        for s in range(2):
+            E.check(eng.lib.somhip_som_batch_update(shards[s].h, ds.h, C.byref(p), it0, 64, first, kb[2]))
+    eng.sync()
+    got = np.concatenate([shards[0].download(), shards[1].download()], axis=0)
+    assert np.array_equal(bits(got), bits(oc))
+    for k in kb:
+        eng.device_free(k)
