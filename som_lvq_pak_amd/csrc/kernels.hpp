@@ -806,7 +806,7 @@ __global__ void k_decode_winners(const uint64_t *__restrict__ keys, const StepSc
 //   cnt[g]                 number of entries
 //   ent[g*count + k]       {sample index in the run, member mask}
 // =====================================================================================
-struct MemberEntry { uint32_t sample; uint32_t pad; unsigned long long mask; };
+struct MemberEntry { uint32_t sample; float alpha; unsigned long long mask; };   // alpha: the iteration's rate
 
 template <bool GAUSS>
 __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
@@ -845,13 +845,42 @@ __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
       if (w.x >= 0 && w.y + s.reach >= g_ty0 && w.y - s.reach <= g_ty1 &&
           (GAUSS || (w.x + s.reach >= g_txa && w.x - s.reach <= g_tx1))) {
         if (GAUSS) m = live_mask;
-        else if (cb.patch_w) {
-          for (int u = 0; u < 64; u++) {
-            const int tx = g_tx0 + (u & 7), ty = g_ty0 + (u >> 3);
-            const float lsq = small_map ? lattice_sq_small(cb.topol, w.x, w.y, tx, ty)
-                                        : lattice_sq(cb.topol, w.x, w.y, tx, ty);
-            if (lsq <= s.thresh) m |= 1ull << u;
+        else if (cb.patch_w && small_map) {
+          // 8x8 patch, exact integer form: with every lattice quantity a multiple of 1/4,
+          //   lattice_sq <= thresh  <=>  (2dx)^2 + 3 dy^2 <= floor(4 thresh)   (hexa)
+          //                              dx^2 + dy^2     <= floor(thresh)     (rect)
+          // and in one lattice row the members are a contiguous run of tx.
+          const bool rect = cb.topol == 4;
+          const int K = static_cast<int>(floor(static_cast<double>(s.thresh) * (rect ? 1.0 : 4.0)));
+          if (K >= 0) {
+#pragma unroll
+            for (int iy = 0; iy < 8; iy++) {
+              const int ty = g_ty0 + iy, dy = w.y - ty;
+              const int rem = K - (rect ? dy * dy : 3 * dy * dy);
+              if (rem < 0) continue;
+              int W = static_cast<int>(sqrtf(static_cast<float>(rem)));      // integer sqrt, corrected
+              while ((W + 1) * (W + 1) <= rem) W++;
+              while (W * W > rem) W--;
+              // rect: |bx - tx| <= W.  hexa: |2(bx - tx) + o| <= W, o = 0 on same-parity rows,
+              // -1 when by is even, +1 when by is odd (som_rout.c:440-447)
+              int lo, hi;
+              if (rect) { lo = w.x - W; hi = w.x + W; }
+              else {
+                const int o = (dy & 1) ? ((w.y & 1) ? 1 : -1) : 0;
+                // 2 bx + o - W <= 2 tx <= 2 bx + o + W
+                const int a = 2 * w.x + o - W, b = 2 * w.x + o + W;
+                lo = (a + (a >= 0 ? 1 : 0)) / 2; if (2 * lo < a) lo++;      // ceil(a / 2)
+                hi = b >= 0 ? b / 2 : -((-b + 1) / 2);                       // floor(b / 2)
+              }
+              lo = lo < g_tx0 ? g_tx0 : lo;
+              hi = hi > g_tx0 + 7 ? g_tx0 + 7 : hi;
+              if (lo <= hi) {
+                const unsigned long long run = ((1ull << (hi - lo + 1)) - 1) << (lo - g_tx0);
+                m |= run << (8 * iy);
+              }
+            }
           }
+        } else if (cb.patch_w) {
         } else {
           int tx = g_tx0, ty = g_ty0;
           for (int u = 0; u < nlive; u++) {
@@ -871,7 +900,7 @@ __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
     for (int w2 = 0; w2 < wave; w2++) off += s_wcount[w2];
     if (on) {
       MemberEntry e;
-      e.sample = static_cast<uint32_t>(b); e.pad = 0; e.mask = m;
+      e.sample = static_cast<uint32_t>(b); e.alpha = sc[b].alpha; e.mask = m;
       out[off + __popcll(bal & ((1ull << lane) - 1))] = e;
       rows_total += __popcll(m);
       pairs_total += 1;

@@ -713,9 +713,32 @@ extern "C" int somhip_find_winners(somhip_codebook *cb, somhip_dataset *ds, int6
 // ---------------------------------------------------------------------------------
 // som_training
 // ---------------------------------------------------------------------------------
+// Bubble threshold for maps with both sides <= 1024: every squared lattice distance is then an exact
+// multiple of 1/4, so only K = floor(4 T) matters (T = bubble_threshold(radius)) and K/4 is an
+// equivalent threshold.  K is constant while the radius stays inside [f(K/4), f((K+1)/4)), f(r) =
+// (float)sqrt((double)r) -- the schedule moves the radius by ~1e-4 per iteration, so the exact
+// search runs only when a lattice distance is crossed.
+struct ThreshCache {
+  bool valid = false;
+  float lo = 0.f, hi = 0.f, thresh = -1.f;
+  float get(float radius) {
+    if (!(radius >= 0.0f)) return -1.0f;
+    if (valid && radius >= lo && radius < hi) return thresh;
+    const float T = bubble_threshold(radius);
+    const double k = std::floor(4.0 * (double)T);
+    thresh = (float)(k / 4.0);
+    lo = (float)std::sqrt(k / 4.0);
+    hi = (float)std::sqrt((k + 1.0) / 4.0);
+    valid = hi > lo;
+    return thresh;
+  }
+};
+
 static int som_scalars(const somhip_codebook *cb, const somhip_dataset *ds, const somhip_som_params *p,
                        int64_t it0, int64_t cnt, int64_t row0, StepScalars *out) {
   const bool gauss = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN;
+  const bool small_map = cb->v.xdim <= 1024 && cb->ydim <= 1024;
+  ThreshCache tc;
   for (int64_t j = 0; j < cnt; j++) {
     int64_t le = it0 + j, r = (row0 + j) % ds->n;
     float trad = radius_at(le, p->length, p->radius);
@@ -724,7 +747,7 @@ static int som_scalars(const somhip_codebook *cb, const somhip_dataset *ds, cons
     if (w > 0.0f && p->use_weights) talp = weighted_alpha(talp, w);
     StepScalars s;
     s.alpha = talp;
-    s.thresh = gauss ? trad : bubble_threshold(trad);
+    s.thresh = gauss ? trad : (small_map ? tc.get(trad) : bubble_threshold(trad));
     s.fixed = -1;
     // lattice rows a neighbourhood of this radius can span: hexa rows are sqrt(0.75)
     // apart (som_rout.c:451), rect rows 1 apart; +1 keeps it conservative
