@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--eval-vectors", type=int, default=8192)
     ap.add_argument("--scan", default="auto", choices=["auto", "direct", "mfma", "mfma_bf16"],
                     help="winner-search implementation (all bit-identical); auto = the engine's default")
+    ap.add_argument("--force-sharded-path", action="store_true",
+                    help="N=1 only: drive the two-phase step from Python as the N>1 path does (host-overhead check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with ranks sharing GPUs (keys staged through the host)")
     ap.add_argument("--online-vectors", type=int, default=-1,
@@ -128,7 +130,7 @@ def main():
     ssom = sharded.ShardedSom(gshard, max(B, 1), nvec)
 
     def step(it0, data_first, count, length_):
-        if world == 1:
+        if world == 1 and not a.force_sharded_path:
             p = SomParams(length_, a.alpha, radius, E.ALPHA_LINEAR, 0, 0, max(B, 1), it0, count, data_first)
             E.check(lib.somhip_som_train(cb.h, ds.h, C.byref(p), None, None))
             return
@@ -150,12 +152,14 @@ def main():
     cb.upload(init[r0:r1])
 
     # ---- timed region: one complete training run of K*B vectors ----
+    if world > 1:      # N > 1: steps are short; event only the two kernels the roofline lines need
+        eng.timing_select({"k_som_update_run", "k_dist_mfma_bf16", "k_dist_mfma", "k_scan_exact"})
     eng.timing(True)
     eng.timing_reset()
     stats_before = eng.scan_stats()
     barrier()
     t0 = time.perf_counter()
-    if world == 1:
+    if world == 1 and not a.force_sharded_path:
         # the K steps (mini-batches) in one call of the epoch-level entry point, as a host tool makes it
         step(0, 0, K * B, length)
     else:

@@ -174,6 +174,8 @@ int  somhip_copy_to_device(somhip_engine *e, void *dev_dst, const void *host_src
  * (used by bench.py for the roofline line).  name = one of the kernel names
  * returned by somhip_kernel_name(i), i in [0, somhip_kernel_count()). */
 int  somhip_timing_enable(somhip_engine *e, int on);
+/* restrict the events to the kernels whose bit (1 << kernel id) is set; default all */
+int  somhip_timing_select(somhip_engine *e, uint64_t kernel_mask);
 int  somhip_timing_reset(somhip_engine *e);
 int  somhip_kernel_count(void);
 const char *somhip_kernel_name(int i);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "somhip_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "somhip_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "somhip_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "somhip_timing_select": (C.c_int, [C.c_void_p, C.c_uint64]),
     "somhip_timing_reset": (C.c_int, [C.c_void_p]),
     "somhip_kernel_count": (C.c_int, []),
     "somhip_kernel_name": (C.c_char_p, [C.c_int]),

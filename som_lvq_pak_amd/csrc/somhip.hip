@@ -91,6 +91,7 @@ struct somhip_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   bool timing = false;
+  uint64_t timing_mask = ~0ull;              // which kernel ids get events when timing is on
   int scan_mode = SOMHIP_SCAN_MFMA_BF16;
   double tau_scale = 1.0;                    // >= 1: widen the pre-filter window (experiments only)
   unsigned long long *d_stats = nullptr;     // [4] re-rank statistics (device)
@@ -169,7 +170,7 @@ struct LaunchTimer {   // HIP events on the engine's own stream around one launc
   hipEvent_t a = nullptr, b = nullptr;
   bool on = false;
   LaunchTimer(somhip_engine *e_, int kid_) : e(e_), kid(kid_) {
-    if (!e->timing) return;
+    if (!e->timing || !((e->timing_mask >> kid_) & 1ull)) return;
     auto get = [&](hipEvent_t *ev) {
       if (!e->pool.empty()) { *ev = e->pool.back(); e->pool.pop_back(); return true; }
       return hipEventCreate(ev) == hipSuccess;
@@ -240,6 +241,7 @@ extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[6]) {
   return 0;
 }
 extern "C" int somhip_timing_enable(somhip_engine *e, int on) { CHK(timing_flush(e)); e->timing = on != 0; return 0; }
+extern "C" int somhip_timing_select(somhip_engine *e, uint64_t kernel_mask) { e->timing_mask = kernel_mask; return 0; }
 extern "C" int somhip_timing_reset(somhip_engine *e) {
   CHK(timing_flush(e));
   for (int i = 0; i < KID_COUNT; i++) { e->launches[i] = 0; e->total_ms[i] = 0; }

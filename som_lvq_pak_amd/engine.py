@@ -68,6 +68,14 @@ class Engine:
     def timing(self, on=True):
         check(self.lib.somhip_timing_enable(self.h, int(on)))
 
+    def timing_select(self, names=None):
+        """time only the named kernels (None = all): fewer HIP events on the stream"""
+        mask = 0
+        for i in range(self.lib.somhip_kernel_count()):
+            if names is None or self.lib.somhip_kernel_name(i).decode() in names:
+                mask |= 1 << i
+        check(self.lib.somhip_timing_select(self.h, mask))
+
     def timing_reset(self):
         check(self.lib.somhip_timing_reset(self.h))
 
