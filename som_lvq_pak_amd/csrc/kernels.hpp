@@ -921,6 +921,25 @@ __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
   }
 }
 
+// K4c: launch order for K4 -- row groups by member count, heaviest first, so the long
+// workgroups start early and the tail of the launch is made of short ones (rank by counting;
+// ties by index).  order[rank] = group.
+__global__ __launch_bounds__(256) void k_order_groups(const uint32_t *__restrict__ cnt, int ngroups,
+                                                      uint32_t *__restrict__ order) {
+  __shared__ uint32_t s_cnt[8192];                     // host guarantees ngroups <= 8192
+  for (int k = threadIdx.x; k < ngroups; k += blockDim.x) s_cnt[k] = cnt[k];
+  __syncthreads();
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ngroups) return;
+  const uint32_t mine = s_cnt[g];
+  uint32_t rank = 0;
+  for (int k = 0; k < ngroups; k++) {
+    const uint32_t c = s_cnt[k];                       // broadcast read
+    rank += (c > mine) || (c == mine && k < g);
+  }
+  order[rank] = static_cast<uint32_t>(g);
+}
+
 // =====================================================================================
 // K4: in-order neighbourhood update of a run of samples, driven by K4b's member lists.
 //
@@ -942,7 +961,8 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
                                                         const int2 *__restrict__ bxy,
                                                         const StepScalars *__restrict__ sc,
                                                         const uint32_t *__restrict__ cnt,
-                                                        const MemberEntry *__restrict__ ent) {
+                                                        const MemberEntry *__restrict__ ent,
+                                                        const uint32_t *__restrict__ order) {
   constexpr int BQ = 4 * QW;                          // chunks per workgroup
   __shared__ float4 xs[TB][BQ];
   __shared__ uint32_t ms[MASKED ? TB : 1][MASKED ? BQ : 1];   // 4 mask bits per chunk
@@ -953,7 +973,7 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
   __shared__ int s_bx[TB], s_by[TB];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t g = blockIdx.x;
+  const int64_t g = order ? order[blockIdx.x] : blockIdx.x;     // heaviest groups first
   const uint32_t n_ent = cnt[g];
   if (n_ent == 0) return;                             // nothing in this run touches the group
   const int qblk = blockIdx.y * BQ;

@@ -906,12 +906,22 @@ static int som_update_run(somhip_codebook *cb, somhip_dataset *ds, int64_t data_
                             (const int2 *)dbxy, d_sc, (uint32_t *)dcnt, (MemberEntry *)dent, e->d_stats);
   }
   HIPCHK(hipGetLastError());
+  uint32_t *dorder = nullptr;
+  if (cb->v.ngroups <= 8192 && !getenv("SOMHIP_NO_ORDER")) {
+    void *p_;
+    CHK(engine_scratch(e, 0, sizeof(uint32_t) * (size_t)cb->v.ngroups, &p_));
+    dorder = (uint32_t *)p_;
+    LaunchTimer t(e, KID_DECODE);
+    hipLaunchKernelGGL(k_order_groups, dim3((unsigned)((cb->v.ngroups + 255) / 256)), dim3(256), 0, e->stream,
+                       (const uint32_t *)dcnt, (int)cb->v.ngroups, dorder);
+    HIPCHK(hipGetLastError());
+  }
   dim3 grid((unsigned)cb->v.ngroups, (unsigned)((cb->v.d4 + 4 * QW - 1) / (4 * QW)));
   LaunchTimer t(e, KID_SOM_UPDATE_RUN);
 #define GO(GG, MM)                                                                                   \
   hipLaunchKernelGGL((k_som_update_run<QW, TB, GG, MM>), grid, dim3(256), 0, e->stream, cb->v, ds->d_rows, \
                      (const uint8_t *)ds->d_mask, ds->n, data_first, count, (const int2 *)dbxy, d_sc,   \
-                     (const uint32_t *)dcnt, (const MemberEntry *)dent)
+                     (const uint32_t *)dcnt, (const MemberEntry *)dent, (const uint32_t *)dorder)
   if (G && M) GO(true, true); else if (G) GO(true, false); else if (M) GO(false, true); else GO(false, false);
 #undef GO
   HIPCHK(hipGetLastError());
