@@ -835,12 +835,19 @@ __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
   uint32_t base = 0;
   unsigned long long rows_total = 0, pairs_total = 0;
 
-  for (int64_t b0 = 0; b0 < count; b0 += 256) {
-    const int64_t b = b0 + tid;
-    unsigned long long m = 0;
-    if (b < count) {
+  constexpr int RR = 4;                 // samples per thread and trip: their loads are issued together
+  for (int64_t b0 = 0; b0 < count; b0 += 256 * RR) {
+    unsigned long long mm[RR];
+    float al[RR];
+#pragma unroll
+    for (int r = 0; r < RR; r++) {
+      const int64_t b = b0 + 256 * r + tid;
+      unsigned long long m = 0;
+      float alpha_b = 0.f;
+      if (b < count) {
       const int2 w = bxy[b];
       const StepScalars s = sc[b];
+      alpha_b = s.alpha;
       // reach (rows) >= radius/0.866 + 1 also bounds the x extent (unit spacing 1, half-unit shifts)
       if (w.x >= 0 && w.y + s.reach >= g_ty0 && w.y - s.reach <= g_ty1 &&
           (GAUSS || (w.x + s.reach >= g_txa && w.x - s.reach <= g_tx1))) {
@@ -881,6 +888,10 @@ __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
             }
           }
         } else if (cb.patch_w) {
+          for (int u = 0; u < 64; u++) {                 // maps wider than 1024: per-unit test
+            const int tx = g_tx0 + (u & 7), ty = g_ty0 + (u >> 3);
+            if (lattice_sq(cb.topol, w.x, w.y, tx, ty) <= s.thresh) m |= 1ull << u;
+          }
         } else {
           int tx = g_tx0, ty = g_ty0;
           for (int u = 0; u < nlive; u++) {
@@ -892,21 +903,30 @@ __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
         }
       }
     }
-    const bool on = m != 0;
-    const unsigned long long bal = __ballot(on);
-    if (lane == 0) s_wcount[wave] = __popcll(bal);
-    __syncthreads();
-    uint32_t off = base;
-    for (int w2 = 0; w2 < wave; w2++) off += s_wcount[w2];
-    if (on) {
-      MemberEntry e;
-      e.sample = static_cast<uint32_t>(b); e.alpha = sc[b].alpha; e.mask = m;
-      out[off + __popcll(bal & ((1ull << lane) - 1))] = e;
-      rows_total += __popcll(m);
-      pairs_total += 1;
+      mm[r] = m;
+      al[r] = alpha_b;
     }
-    base += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
-    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RR; r++) {
+      if (b0 + 256 * r >= count) break;                 // uniform
+      const int64_t b = b0 + 256 * r + tid;
+      const unsigned long long m = mm[r];
+      const bool on = m != 0;
+      const unsigned long long bal = __ballot(on);
+      if (lane == 0) s_wcount[wave] = __popcll(bal);
+      __syncthreads();
+      uint32_t off = base;
+      for (int w2 = 0; w2 < wave; w2++) off += s_wcount[w2];
+      if (on) {
+        MemberEntry e;
+        e.sample = static_cast<uint32_t>(b); e.alpha = al[r]; e.mask = m;
+        out[off + __popcll(bal & ((1ull << lane) - 1))] = e;
+        rows_total += __popcll(m);
+        pairs_total += 1;
+      }
+      base += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+      __syncthreads();
+    }
   }
   if (tid == 0) cnt[g] = base;
   // instrumentation: (row, iteration) updates and (row group, iteration) pairs of this run
@@ -1366,7 +1386,25 @@ __global__ __launch_bounds__(256) void k_rerank_pairs(CbView cb, const float *__
   const float *x = rows + ((first + pr.x) % n_rows) * cb.d;
   const bool vec = (cb.d & 3) == 0;
   float acc = 0.0f;
-  for (int q = 0; q < cb.d4; q++) {
+  // 8 chunks of the row and of the sample in flight per lane (independent loads first)
+  constexpr int UP = 8;
+  int q = 0;
+  for (; q + UP <= cb.d4; q += UP) {
+    float4 cc[UP], xx[UP];
+#pragma unroll
+    for (int u = 0; u < UP; u++) {
+      cc[u] = crow[static_cast<int64_t>(q + u) * WAVE];
+      xx[u] = vec ? reinterpret_cast<const float4 *>(x)[q + u] : load_x4<false>(x, q + u, cb.d);
+    }
+#pragma unroll
+    for (int u = 0; u < UP; u++) {
+      acc = sq_acc(acc, cc[u].x, xx[u].x);
+      acc = sq_acc(acc, cc[u].y, xx[u].y);
+      acc = sq_acc(acc, cc[u].z, xx[u].z);
+      acc = sq_acc(acc, cc[u].w, xx[u].w);
+    }
+  }
+  for (; q < cb.d4; q++) {
     const float4 c = crow[static_cast<int64_t>(q) * WAVE];
     const float4 xv = vec ? reinterpret_cast<const float4 *>(x)[q] : load_x4<false>(x, q, cb.d);
     acc = sq_acc(acc, c.x, xv.x);

@@ -458,3 +458,16 @@ def test_patch_row_order_masks_fixed_weights_and_shards(eng, E, oracle):
     assert np.array_equal(bits(got), bits(oc))
     for k in kb:
         eng.device_free(k)
+
+
+@pytest.mark.parametrize("batch", [1, 32])
+def test_map_wider_than_1024_uses_the_general_lattice_path(eng, E, oracle, batch):
+    """sides > 1024: the fp32-only / integer lattice shortcuts do not apply (values no longer exact
+    multiples of 1/4 below 2^22 in general), the per-unit mixed fp32/fp64 form must be used"""
+    x, _ = synth(91, 300, 3)
+    ini = oracle.randinit(x, 1032, 8, 2)
+    oc, oi, od = oracle.som_train(ini, 1032, 8, 3, 1, x, 160, 0.2, 300.0, batch=batch)
+    cb, ds = E.Codebook(eng, ini, 3, 1, 1032, 8), E.Dataset(eng, x)
+    ti, td = E.som_train(cb, ds, 160, 0.2, 300.0, batch=batch)
+    assert np.array_equal(ti, oi) and np.array_equal(bits(td), bits(od))
+    assert np.array_equal(bits(cb.download()), bits(oc))
