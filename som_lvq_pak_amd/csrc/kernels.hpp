@@ -658,33 +658,44 @@ __global__ __launch_bounds__(256, 2) void k_dist_mfma_bf16(CbView cb, int d8,
   const int64_t st0 = static_cast<int64_t>(blockIdx.x) * 4;
   const int64_t nst = bpad / 32;
 
-  // 64 pieces of 1 KiB per stage, 16 per wave
-  const uint4 *src[16];
-  int dst[16], stride[16], kbl[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int p = wave * 16 + i;
-    if (p < 32) {
-      const int arr = p >> 4, gi = (p >> 3) & 1, kb = p & 7;
-      const int64_t g = g0 + gi < cb.ngroups ? g0 + gi : cb.ngroups - 1;
-      src[i] = (arr ? clo : chi) + (g * d8 + kb) * 64 + lane;
-      dst[i] = (arr ? CL : CH) + (gi * BF_KB + kb) * 64 + lane;
-      stride[i] = BF_KB * 64;
-      kbl[i] = kb;
-    } else {
-      const int pp = p - 32, arr = pp >> 4, ti = (pp >> 2) & 3, kp = pp & 3;
-      const int64_t st = st0 + ti < nst ? st0 + ti : nst - 1;
-      src[i] = (arr ? xlo : xhi) + (st * d8 + 2 * kp) * 32 + lane;
-      dst[i] = (arr ? XL : XH) + (ti * BF_KB + 2 * kp) * 32 + lane;
-      stride[i] = BF_KB * 32;
-      kbl[i] = 2 * kp + half;
-    }
-  }
+  // 64 pieces of 1 KiB per stage, 16 per wave, laid out so that everything but four base
+  // pointers is a compile-time constant:
+  //   wave w stages array (w & 1 ? lo : hi) of code group (w >> 1)      : 8 k-blocks
+  //                 and of sample tiles 2(w >> 1), 2(w >> 1) + 1         : 4 k-block pairs each
+  const int arr = wave & 1, sel = wave >> 1;
+  const int64_t gsrc = g0 + sel < cb.ngroups ? g0 + sel : cb.ngroups - 1;
+  const int64_t t0s = st0 + 2 * sel < nst ? st0 + 2 * sel : nst - 1;
+  const int64_t t1s = st0 + 2 * sel + 1 < nst ? st0 + 2 * sel + 1 : nst - 1;
+  const uint4 *pc = (arr ? clo : chi) + (gsrc * d8) * 64 + lane;          // + kb * 64
+  const uint4 *px0 = (arr ? xlo : xhi) + (t0s * d8) * 32 + lane;         // + kp * 64 (two k-blocks)
+  const uint4 *px1 = (arr ? xlo : xhi) + (t1s * d8) * 32 + lane;
+  const int dc = (arr ? CL : CH) + (sel * BF_KB) * 64 + lane;             // + kb * 64
+  const int dx0 = (arr ? XL : XH) + ((2 * sel) * BF_KB) * 32 + lane;      // + kp * 64
+  const int dx1 = (arr ? XL : XH) + ((2 * sel + 1) * BF_KB) * 32 + lane;
   const int nstage = (d8 + BF_KB - 1) / BF_KB;
   auto stage_load = [&](uint4 (&r)[16], int s) {
+    const int kb0 = s * BF_KB;
+    if (kb0 + BF_KB <= d8) {                      // full stage (wave-uniform): no per-piece predicates
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-      r[i] = (s * BF_KB + kbl[i] < d8) ? src[i][static_cast<int64_t>(s) * stride[i]] : make_uint4(0u, 0u, 0u, 0u);
+      for (int k = 0; k < 8; k++) r[k] = pc[(kb0 + k) * 64];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { r[8 + k] = px0[(kb0 + 2 * k) * 32]; r[12 + k] = px1[(kb0 + 2 * k) * 32]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) r[k] = kb0 + k < d8 ? pc[(kb0 + k) * 64] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool ok = kb0 + 2 * k + half < d8;
+        r[8 + k] = ok ? px0[(kb0 + 2 * k) * 32] : make_uint4(0u, 0u, 0u, 0u);
+        r[12 + k] = ok ? px1[(kb0 + 2 * k) * 32] : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  auto stage_store = [&](const uint4 (&r)[16]) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) lds[dc + k * 64] = r[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { lds[dx0 + k * 64] = r[8 + k]; lds[dx1 + k * 64] = r[12 + k]; }
   };
 
   f32x16 acc[2][2];
@@ -698,8 +709,7 @@ __global__ __launch_bounds__(256, 2) void k_dist_mfma_bf16(CbView cb, int d8,
   uint4 regs[16];
   stage_load(regs, 0);
   for (int s = 0; s < nstage; s++) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) lds[dst[i]] = regs[i];
+    stage_store(regs);
     __syncthreads();
     if (s + 1 < nstage) stage_load(regs, s + 1);
 #pragma unroll
