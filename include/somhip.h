@@ -138,7 +138,11 @@ int  somhip_som_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_
 /* ---- lvq1/olvq1/lvq2/lvq3_training (lvq_rout.c:498,584,702,808) --------------
  * kind = SOMHIP_LVQ1..LVQ3.  talpha (host, [n_rows], in/out) = OLVQ1's per-code
  * rates, initialised by the caller the way lvq_rout.c:614-627 does; `alpha` is also
- * OLVQ1's clamp (:671).  Online (batch 1) only in this version.  The trace has knn
+ * OLVQ1's clamp (:671).  The result is the online (one sample at a time) result of the
+ * reference, bit for bit; internally the loop runs as exact speculative batches (one
+ * frozen-codebook scan per batch, samples certified and applied in order; see
+ * kernels.hpp K6) unless SOMHIP_LVQ_ONLINE=1 or a row does not fit the on-chip cache
+ * (dim > 2048), in which case every iteration is its own launch.  The trace has knn
  * entries per iteration (knn = 2 for LVQ2/LVQ3, else 1). */
 typedef struct somhip_lvq_params {
   int32_t kind;
@@ -151,6 +155,11 @@ typedef struct somhip_lvq_params {
 } somhip_lvq_params;
 int  somhip_lvq_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_lvq_params *p,
                       float *talpha, int32_t *trace_index, float *trace_diff);
+/* out[0] = codebook rescans (batches) done by somhip_lvq_train so far, out[1] = samples,
+ * out[2] / out[3] = batches cut short because a sample's candidate list was exhausted /
+ * the on-chip row cache was full, out[4..7] = 100 MHz ticks the in-order kernel spent in
+ * its phases (inputs, cached-row distances, decision, correction) */
+int  somhip_lvq_stats(somhip_engine *e, uint64_t out[8]);
 
 /* ---- two-phase mini-batch primitives (what somhip_som_train(batch>1) is made of;
  * exposed so a multi-GPU host can put its collective between them) -------------

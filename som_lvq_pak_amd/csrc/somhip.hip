@@ -65,13 +65,14 @@ enum KernelId {
   KID_RERANK_SELECT,
   KID_RERANK_PAIRS,
   KID_DIST_MFMA_BF16,
+  KID_LVQ_BATCH_APPLY,
   KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {
     "k_scan_exact", "k_som_update_run", "k_som_online_step", "k_lvq_online_step",
     "k_pack_samples", "k_merge_topk", "k_scan_masked", "k_layout", "k_decode_winners",
     "k_dist_mfma", "k_rerank", "k_norms_tau", "k_som_members",
-    "k_rerank_select", "k_rerank_pairs", "k_dist_mfma_bf16"};
+    "k_rerank_select", "k_rerank_pairs", "k_dist_mfma_bf16", "k_lvq_batch_apply"};
 extern "C" int somhip_kernel_count(void) { return KID_COUNT; }
 extern "C" const char *somhip_kernel_name(int i) { return (i >= 0 && i < KID_COUNT) ? kKernelNames[i] : ""; }
 
@@ -96,6 +97,8 @@ struct somhip_engine {
   double tau_scale = 1.0;                    // >= 1: widen the pre-filter window (experiments only)
   unsigned long long *d_stats = nullptr;     // [4] re-rank statistics (device)
   uint64_t samples_searched = 0;
+  uint64_t lvq_batches = 0, lvq_samples = 0;   // exact batched LVQ: rescans and samples
+  uint64_t lvq_stop_list = 0, lvq_stop_cache = 0, lvq_cycles[4] = {0, 0, 0, 0};   // batches ended by an exhausted candidate list / a full cache
   // ring of pinned host staging buffers for per-batch scalars (H2D without a host sync)
   void *pin_buf[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pin_bytes[4] = {0, 0, 0, 0};
@@ -238,6 +241,12 @@ extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[6]) {
   HIPCHK(hipMemcpyAsync(h, e->d_stats, sizeof h, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = e->samples_searched; out[4] = h[3]; out[5] = h[4];
+  return 0;
+}
+extern "C" int somhip_lvq_stats(somhip_engine *e, uint64_t out[8]) {
+  if (!e || !out) return fail("somhip_lvq_stats: null argument");
+  out[0] = e->lvq_batches; out[1] = e->lvq_samples; out[2] = e->lvq_stop_list; out[3] = e->lvq_stop_cache;
+  for (int k = 0; k < 4; k++) out[4 + k] = e->lvq_cycles[k];
   return 0;
 }
 extern "C" int somhip_timing_enable(somhip_engine *e, int on) { CHK(timing_flush(e)); e->timing = on != 0; return 0; }
@@ -609,7 +618,7 @@ static int scan_keys_top1(somhip_codebook *cb, somhip_dataset *ds, int64_t first
 
 template <int K>
 static int scan_keys_topk(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
-                          uint64_t *d_keys /*[count][K]*/) {
+                          uint64_t *d_keys /*[count][K]*/, int tie_knn = 1) {
   somhip_engine *e = cb->e;
   int64_t nsb = (count + SCAN_S - 1) / SCAN_S;
   int nblk = (int)((cb->v.ngroups + 3) / 4);
@@ -626,7 +635,7 @@ static int scan_keys_topk(somhip_codebook *cb, somhip_dataset *ds, int64_t first
     LaunchTimer t(e, KID_SCAN_EXACT);
     dim3 grid((unsigned)nsb, (unsigned)nblk);
     hipLaunchKernelGGL((k_scan_exact<SCAN_S, 1, K>), grid, dim3(256), 0, e->stream, cb->v,
-                       (const float4 *)xt, count, 1, (uint64_t *)nullptr, (uint64_t *)part);
+                       (const float4 *)xt, count, tie_knn, (uint64_t *)nullptr, (uint64_t *)part);
   }
   HIPCHK(hipGetLastError());
   {
@@ -1006,6 +1015,97 @@ extern "C" int somhip_som_train(somhip_codebook *cb, somhip_dataset *ds, const s
 // ---------------------------------------------------------------------------------
 // lvq*_training
 // ---------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------
+// lvq1/olvq1/lvq2/lvq3_training, exact batched form (kernels.hpp K6): per batch one
+// frozen-codebook top-8 scan, then k_lvq_batch_apply walks the samples in order.  The
+// device tells how many samples it could certify (ctl.consumed); the next batch starts
+// there.  Bit-identical to the online loop.
+// ---------------------------------------------------------------------------------
+static int lvq_cache_slots(int d4) {
+  const int64_t budget = 152 * 1024;                 // dynamic LDS; ~6.5 KiB static on top (160 KiB per workgroup)
+  int64_t s = (budget - 3 * (int64_t)d4 * 16) / ((int64_t)d4 * 16);
+  return (int)std::min<int64_t>(s, LVQ_BT);
+}
+
+static int lvq_train_batched(somhip_codebook *cb, somhip_dataset *ds, const somhip_lvq_params *p, int knn,
+                             float *talpha, int32_t *trace_index, float *trace_diff) {
+  somhip_engine *e = cb->e;
+  const int slots = lvq_cache_slots(cb->v.d4);
+  const size_t dyn = ((size_t)cb->v.d4 * slots + 3 * (size_t)cb->v.d4) * sizeof(float4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void *)k_lvq_batch_apply, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    attr_set = true;
+  }
+  const int64_t BMAX = 1024;
+  void *dcand, *dfin, *dst, *dctl;
+  CHK(engine_scratch(e, 3, sizeof(uint64_t) * (size_t)BMAX * LVQ_K0, &dcand));
+  CHK(engine_scratch(e, 4, sizeof(LvqStep) * (size_t)BMAX, &dst));
+  CHK(engine_scratch(e, 5, sizeof(uint64_t) * (size_t)BMAX * 2, &dfin));
+  CHK(engine_scratch(e, 6, sizeof(LvqBatchCtl), &dctl));
+  std::vector<LvqStep> hst((size_t)BMAX);
+  std::vector<uint64_t> hfin((size_t)BMAX * 2);
+  const float ratio = (1 - p->winlen) / (1 + p->winlen);                  // lvq_rout.c:770, fp32
+  const bool want_trace = trace_index || trace_diff;
+  int64_t B = std::min<int64_t>(BMAX, std::max<int64_t>(32, slots));
+  int64_t off = 0;
+  uint64_t n_batches = 0;
+  while (off < p->count) {
+    const int64_t c = std::min(B, p->count - off);
+    const int64_t it0 = p->start_iter + off, row0 = (p->data_first + off) % ds->n;
+    for (int64_t j = 0; j < c; j++) {
+      LvqStep s;
+      s.kind = p->kind;
+      s.alpha = alpha_at(p->alpha_type, it0 + j, p->length, p->alpha);
+      s.alpha_clamp = p->alpha;
+      s.win_ratio = ratio;
+      s.epsilon = p->epsilon;
+      s.label = ds->labels[(size_t)((row0 + j) % ds->n)];
+      hst[(size_t)j] = s;
+    }
+    HIPCHK(hipMemcpyAsync(dst, hst.data(), sizeof(LvqStep) * (size_t)c, hipMemcpyHostToDevice, e->stream));
+    CHK(scan_keys_topk<LVQ_K0>(cb, ds, row0, c, (uint64_t *)dcand, knn == 2 ? 1 : 0));
+    {
+      LaunchTimer t(e, KID_LVQ_BATCH_APPLY);
+      hipLaunchKernelGGL(k_lvq_batch_apply, dim3(1), dim3(LVQ_BT), dyn, e->stream, cb->v, ds->d_rows, ds->n, row0,
+                         (int)c, (const int32_t *)cb->d_labels, p->kind == SOMHIP_OLVQ1 ? cb->d_talpha : nullptr,
+                         (const uint64_t *)dcand, (const LvqStep *)dst, knn, slots, (uint64_t *)dfin,
+                         (LvqBatchCtl *)dctl);
+    }
+    HIPCHK(hipGetLastError());
+    LvqBatchCtl ctl;
+    HIPCHK(hipMemcpyAsync(&ctl, dctl, sizeof(ctl), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (ctl.consumed < 0 || ctl.consumed > c) return fail("somhip_lvq_train: bad batch control block");
+    if (ctl.consumed == 0) {
+      // cannot happen: with an empty cache every winner comes from the frozen list and one
+      // or two slots always fit; refuse to spin
+      return fail("somhip_lvq_train: batch made no progress (reason %d)", ctl.reason);
+    }
+    if (want_trace) {
+      HIPCHK(hipMemcpy(hfin.data(), dfin, sizeof(uint64_t) * 2 * (size_t)ctl.consumed, hipMemcpyDeviceToHost));
+      for (int64_t j = 0; j < ctl.consumed; j++)
+        for (int k = 0; k < knn; k++) {
+          int32_t idx; float df;
+          decode_key(hfin[(size_t)(2 * j + k)], knn == 2, &idx, &df);
+          if (trace_index) trace_index[(off + j) * knn + k] = idx;
+          if (trace_diff) trace_diff[(off + j) * knn + k] = df;
+        }
+    }
+    off += ctl.consumed;
+    n_batches++;
+    if (ctl.reason == 1) e->lvq_stop_list++;
+    if (ctl.reason == 2) e->lvq_stop_cache++;
+    for (int k = 0; k < 4; k++) e->lvq_cycles[k] += (uint64_t)ctl.cycles[k];
+    // next batch: a little more than what this one managed (the scan of samples that were not
+    // certified is wasted), never below 32
+    B = std::min<int64_t>(BMAX, std::max<int64_t>(32, (int64_t)ctl.consumed + ctl.consumed / 4 + 8));
+  }
+  e->lvq_batches += n_batches;
+  e->lvq_samples += (uint64_t)p->count;
+  return 0;
+}
+
 extern "C" int somhip_lvq_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_lvq_params *p,
                                 float *talpha, int32_t *trace_index, float *trace_diff) {
   CHK(check_pair(cb, ds, "somhip_lvq_train"));
@@ -1026,6 +1126,15 @@ extern "C" int somhip_lvq_train(somhip_codebook *cb, somhip_dataset *ds, const s
   if (p->kind == SOMHIP_OLVQ1) {
     if (!cb->d_talpha) HIPCHK(hipMalloc((void **)&cb->d_talpha, sizeof(float) * (size_t)cb->v.n));
     HIPCHK(hipMemcpyAsync(cb->d_talpha, talpha, sizeof(float) * (size_t)cb->v.n, hipMemcpyHostToDevice, e->stream));
+  }
+  // exact batched engine unless asked otherwise (SOMHIP_LVQ_ONLINE=1), or the row does not fit the cache
+  if (!getenv("SOMHIP_LVQ_ONLINE") && cb->v.patch_w == 0 && cb->v.d4 <= LVQ_BT && lvq_cache_slots(cb->v.d4) >= 8) {
+    int rc = lvq_train_batched(cb, ds, p, knn, talpha, trace_index, trace_diff);
+    if (rc) return rc;
+    if (p->kind == SOMHIP_OLVQ1)
+      HIPCHK(hipMemcpyAsync(talpha, cb->d_talpha, sizeof(float) * (size_t)cb->v.n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
   }
   const int64_t CH = 4096;
   const int nblk = (int)((cb->v.ngroups + 3) / 4);

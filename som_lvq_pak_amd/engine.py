@@ -64,6 +64,13 @@ class Engine:
         return {"groups": out[0], "rows": out[1], "max_groups_per_sample": out[2], "samples": out[3],
                 "row_updates": out[4], "group_updates": out[5]}
 
+    def lvq_stats(self):
+        """exact batched LVQ: codebook rescans (batches) and samples so far"""
+        out = (C.c_uint64 * 8)()
+        check(self.lib.somhip_lvq_stats(self.h, out))
+        return {"batches": out[0], "samples": out[1], "stop_list": out[2], "stop_cache": out[3],
+                "phase_us": [out[4 + k] / 100.0 for k in range(4)]}
+
     # --- timing table (HIP events on the engine's stream) ---
     def timing(self, on=True):
         check(self.lib.somhip_timing_enable(self.h, int(on)))

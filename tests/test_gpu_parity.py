@@ -3,6 +3,7 @@ fixtures the real reference produced.  Bit-exact: indices equal, fp32 values com
 bit patterns.  Needs an MI355X:  pytest -m gpu."""
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -273,6 +274,70 @@ def test_lvq_random_vs_oracle_and_segments(eng, E, oracle, kind):
     assert np.array_equal(bits(cb.download()), bits(oc))
     if kind == 2:
         assert np.array_equal(bits(tal), bits(ol))
+
+
+def _lvq_both_engines(eng, E, oracle, kind, codes, clab, x, lab, length, alpha, **kw):
+    """exact batched engine (default) and one-launch-per-iteration engine against the oracle"""
+    oc, ol, oi, od = oracle.lvq_train(kind, codes, clab, x, lab, length, alpha, **kw)
+    stats = {}
+    for mode in ("batched", "online"):
+        if mode == "online":
+            os.environ["SOMHIP_LVQ_ONLINE"] = "1"
+        try:
+            cb = E.Codebook(eng, codes, labels=clab)
+            ds = E.Dataset(eng, x, labels=lab)
+            before = eng.lvq_stats()
+            tal, ti, td = E.lvq_train(cb, ds, kind, length, alpha, **kw)
+            after = eng.lvq_stats()
+        finally:
+            os.environ.pop("SOMHIP_LVQ_ONLINE", None)
+        assert np.array_equal(ti, oi), mode
+        assert np.array_equal(bits(td), bits(od)), mode
+        assert np.array_equal(bits(cb.download()), bits(oc)), mode
+        if kind == 2:
+            assert np.array_equal(bits(tal), bits(ol)), mode
+        stats[mode] = {k: after[k] - before[k] for k in after if k != "phase_us"}
+    assert stats["online"]["batches"] == 0 and stats["online"]["samples"] == 0
+    assert stats["batched"]["samples"] == length
+    return stats["batched"]
+
+
+@pytest.mark.parametrize("kind", [1, 2, 3, 4])
+@pytest.mark.parametrize("shape", ["tiny_codebook", "one_cluster", "wide_rows", "odd_dim", "many_codes"])
+def test_lvq_exact_batches_stop_conditions(eng, E, oracle, kind, shape):
+    """The batched LVQ engine must give the online result whatever ends its batches: a codebook
+    smaller than the candidate list, every candidate already corrected (all samples in one
+    cluster of a dozen codes), the row cache full (dim 1000 -> 32 slots), a dim that is not
+    a multiple of 4, and the easy case (many codes, few collisions)."""
+    n, d, m, k, spread, length = {"tiny_codebook": (6, 7, 200, 3, 1.0, 600),
+                                  "one_cluster": (12, 16, 400, 1, 0.3, 1500),
+                                  "wide_rows": (300, 1000, 260, 4, 2.0, 700),
+                                  "odd_dim": (90, 13, 300, 4, 1.5, 1200),
+                                  "many_codes": (3000, 48, 2000, 20, 3.0, 3000)}[shape]
+    x, lab = synth(900 + kind, m, d, k=k, spread=spread)
+    rs = np.random.RandomState(7 * kind + len(shape))
+    if shape == "one_cluster":
+        lab = rs.randint(1, 4, m).astype(lab.dtype)         # mixed labels inside one blob: pushes and pulls
+    if n <= m:
+        pick = rs.choice(m, n, replace=False)
+        codes, clab = x[pick].copy(), lab[pick].copy()
+    else:
+        pick = rs.randint(0, m, n)
+        codes = (x[pick] + 0.05 * rs.randn(n, d)).astype(np.float32)
+        clab = lab[pick].copy()
+    kw = {"winlen": 0.3} if kind >= 3 else {}
+    if kind == 4:
+        kw["epsilon"] = 0.15
+    st = _lvq_both_engines(eng, E, oracle, kind, codes, clab, x, lab, length, 0.08, **kw)
+    assert 1 <= st["batches"] <= length
+    if shape == "one_cluster" and kind <= 2:
+        assert st["stop_list"] > 0              # the case was built to exhaust candidate lists
+    if shape == "wide_rows" and kind <= 2:
+        assert st["stop_cache"] > 0             # ... and this one to fill the 32-slot cache
+    if shape == "tiny_codebook":
+        assert st["stop_list"] == 0             # all rows are listed: nothing can be missed
+    if shape == "many_codes":
+        assert st["batches"] <= length // 20    # the speculation has to pay off somewhere
 
 
 # --------------------------------------------------------------------------- error behaviour

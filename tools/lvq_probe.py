@@ -28,10 +28,22 @@ def main():
     for kind, name, kw in ((E.OLVQ1, "olvq1", dict(alpha=0.3)), (E.LVQ1, "lvq1", dict(alpha=0.05)),
                            (E.LVQ3, "lvq3", dict(alpha=0.05, winlen=0.3, epsilon=0.1))):
         cb = E.Codebook(eng, codes, labels=clab)
+        s0 = eng.lvq_stats()
+        eng.timing_reset()
+        eng.timing(True)
         t0 = time.time()
         E.lvq_train(cb, ds, kind, iters, trace=False, **kw)
         eng.sync()
         dt = time.time() - t0
+        eng.timing(False)
+        s1 = eng.lvq_stats()
+        nb = s1["batches"] - s0["batches"]
+        if nb:
+            print("   exact batches: %d (%.1f samples each; %d ended by the candidate list, %d by the cache); kernels ms: %s"
+                  % (nb, iters / nb, s1["stop_list"] - s0["stop_list"], s1["stop_cache"] - s0["stop_cache"],
+                     {k: round(v[1], 1) for k, v in eng.timing_table().items() if v[0]}))
+            print("   in-order kernel, us per sample by phase (inputs, distances, decision, correction):",
+                  [round((a - b) / iters, 2) for a, b in zip(s1["phase_us"], s0["phase_us"])])
         ds2 = E.Dataset(eng, x[:20000])
         wi, _, _ = E.find_winners(cb, ds2)
         acc = float((clab[wi[:, 0]] == lab[:20000]).mean())
