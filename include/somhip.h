@@ -161,6 +161,14 @@ int  somhip_lvq_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_lvq_
  * its phases (inputs, cached-row distances, decision, correction) */
 int  somhip_lvq_stats(somhip_engine *e, uint64_t out[8]);
 
+/* ---- find_qerror2 (som_rout.c:823-885; bubble_qerror :734-772, gaussian_qerror :775-818):
+ * out[i] = sum over the neighbourhood of sample first+i's winner of (h *) d*d, d =
+ * vector_dist_euc (lvq_pak.c:291-316), accumulated in fp32 in unit order exactly as the
+ * reference does; ret[i] = 0 for samples with every component masked (the reference skips
+ * them, :858).  The caller adds out[] in data order (the reference's float accumulator). */
+int  somhip_qerror2(somhip_codebook *cb, somhip_dataset *ds, float radius, int64_t first,
+                    int64_t count, float *out, int32_t *ret);
+
 /* ---- two-phase mini-batch primitives (what somhip_som_train(batch>1) is made of;
  * exposed so a multi-GPU host can put its collective between them) -------------
  * keys: DEVICE array [count] of uint64 = (fp32 bits of squared distance << 32) |

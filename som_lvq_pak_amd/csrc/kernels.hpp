@@ -62,6 +62,16 @@ __device__ __forceinline__ void txty_of_row(const CbView &cb, int64_t row, int &
   ty = static_cast<int>(static_cast<uint32_t>(cb.row_offset) / xd + py * 8 + (i >> 3));
 }
 
+// local storage row of global unit index `unit` (inverse of unit_of_row)
+__device__ __forceinline__ int64_t row_of_unit(const CbView &cb, uint32_t unit) {
+  const uint32_t u = unit - static_cast<uint32_t>(cb.row_offset);
+  if (cb.patch_w == 0) return static_cast<int64_t>(u);
+  const uint32_t xd = static_cast<uint32_t>(cb.xdim);
+  const uint32_t y = u / xd, x = u % xd;
+  const uint32_t p = (y >> 3) * static_cast<uint32_t>(cb.patch_w) + (x >> 3);
+  return static_cast<int64_t>(p) * 64 + ((y & 7) << 3) + (x & 7);
+}
+
 __device__ __forceinline__ const float4 *tile_ptr(const CbView &cb, int64_t g, int q, int lane) {
   return reinterpret_cast<const float4 *>(cb.tiles) + ((g * cb.d4 + q) * WAVE + lane);
 }
@@ -1932,6 +1942,93 @@ __global__ __launch_bounds__(LVQ_BT) void k_lvq_batch_apply(CbView cb, const flo
     ctl->consumed = j; ctl->nmod = m; ctl->reason = reason; ctl->pad = 0;
     for (int k = 0; k < 4; k++) ctl->cycles[k] = cyc[k];
   }
+}
+
+// =====================================================================================
+// K7: find_qerror2 (som_rout.c:823-885): per sample, the neighbourhood-weighted sum
+//   bubble_qerror   :734-772   q = sum over units u with mapdist(bmu, u) <= radius of d_u * d_u
+//   gaussian_qerror :775-818   q = sum over all units of (exp(-dd^2 / 2 radius^2) * d_u) * d_u
+// with d_u = vector_dist_euc(code_u, sample) (lvq_pak.c:291-316: fp32 sum in dim order, masked
+// components skipped, (float)sqrt((double)sum)), accumulated in fp32 IN UNIT ORDER.  One
+// workgroup per sample; a chunk of 256 consecutive units is evaluated in parallel (thread =
+// unit), then one thread adds the chunk's terms in order.  The host adds the per-sample sums in
+// data order (the reference's outer float accumulator).
+// =====================================================================================
+template <bool GAUSS>
+__global__ __launch_bounds__(256) void k_qerror2(CbView cb, int ydim, const float *__restrict__ rows,
+                                                 const uint8_t *__restrict__ mask, int64_t n_rows,
+                                                 int64_t first, const uint64_t *__restrict__ keys,
+                                                 float radius, float thresh, int reach,
+                                                 float *__restrict__ out) {
+  extern __shared__ float q2_dyn[];
+  float *s_x = q2_dyn;                                   // [d]
+  uint8_t *s_mk = reinterpret_cast<uint8_t *>(q2_dyn + cb.d);   // [d]
+  __shared__ float s_term[256];
+  __shared__ uint8_t s_on[256];
+  const int tid = threadIdx.x;
+  const int64_t smp = blockIdx.x;
+  const uint64_t key = keys[smp];
+  if (static_cast<uint32_t>(key >> 32) >= FLT_MAX_BITS) { if (tid == 0) out[smp] = 0.0f; return; }
+  const int64_t r = (first + smp) % n_rows;
+  for (int i = tid; i < cb.d; i += 256) {
+    s_x[i] = rows[r * cb.d + i];
+    s_mk[i] = mask ? mask[r * cb.d + i] : 0;
+  }
+  const uint32_t widx = static_cast<uint32_t>(key);
+  const int xdim = cb.xdim;
+  const int bx = static_cast<int>(widx % static_cast<uint32_t>(xdim)), by = static_cast<int>(widx / static_cast<uint32_t>(xdim));
+  int64_t u_lo = cb.row_offset, u_hi = cb.row_offset + cb.n;
+  if (!GAUSS) {
+    const int y0 = by - reach < 0 ? 0 : by - reach, y1 = by + reach + 1 > ydim ? ydim : by + reach + 1;
+    const int64_t lo = static_cast<int64_t>(y0) * xdim, hi = static_cast<int64_t>(y1) * xdim;
+    u_lo = lo > u_lo ? lo : u_lo;
+    u_hi = hi < u_hi ? hi : u_hi;
+  }
+  __syncthreads();
+  float q = 0.0f;
+  for (int64_t base = u_lo; base < u_hi; base += 256) {
+    const int64_t u = base + tid;
+    bool on = false;
+    float term = 0.0f;
+    if (u < u_hi) {
+      const int tx = static_cast<int>(u % xdim), ty = static_cast<int>(u / xdim);
+      const float lsq = lattice_sq(cb.topol, bx, by, tx, ty);
+      on = GAUSS || lsq <= thresh;
+      if (on) {
+        const int64_t row = row_of_unit(cb, static_cast<uint32_t>(u));
+        const int64_t g = row >> 6;
+        const int lane = static_cast<int>(row & 63);
+        float acc = 0.0f;
+        for (int qd = 0; qd < cb.d4; qd++) {
+          const float4 c = *tile_ptr(cb, g, qd, lane);
+          const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int i = qd * 4 + k;
+            if (i < cb.d && s_mk[i] == 0) acc = sq_acc(acc, cc[k], s_x[i]);
+          }
+        }
+        const float dv = static_cast<float>(sqrt(static_cast<double>(acc)));
+        if (GAUSS) {
+          const float h = gaussian_alpha(lsq, radius, 1.0f);     // 1.0f * h == h
+          const float t = h * dv;
+          term = t * dv;
+        } else {
+          term = dv * dv;
+        }
+      }
+    }
+    s_term[tid] = term;
+    s_on[tid] = on ? 1 : 0;
+    __syncthreads();
+    if (tid == 0) {
+      const int lim = static_cast<int>(u_hi - base < 256 ? u_hi - base : 256);
+      for (int i = 0; i < lim; i++)
+        if (s_on[i]) q = q + s_term[i];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) out[smp] = q;
 }
 
 __global__ void k_fill_u64(uint64_t *p, int64_t n, uint64_t v) {

@@ -721,6 +721,48 @@ extern "C" int somhip_find_winners(somhip_codebook *cb, somhip_dataset *ds, int6
   return 0;
 }
 
+// find_qerror2 (som_rout.c:823-885): out[i] = the neighbourhood-weighted error of sample first+i
+// (0 where the sample has no winner); the caller adds them in data order, as the reference does.
+extern "C" int somhip_qerror2(somhip_codebook *cb, somhip_dataset *ds, float radius, int64_t first,
+                              int64_t count, float *out, int32_t *ret) {
+  CHK(check_pair(cb, ds, "somhip_qerror2"));
+  if (!out) return fail("somhip_qerror2: null output");
+  if (cb->v.topol != SOMHIP_TOPOL_HEXA && cb->v.topol != SOMHIP_TOPOL_RECT) return fail("somhip_qerror2: can't set SOM parameters");
+  if (cb->v.row_offset != 0 || cb->n_global != cb->v.n) return fail("somhip_qerror2: sharded codebook not supported");
+  if (count <= 0) return 0;
+  somhip_engine *e = cb->e;
+  HIPCHK(hipSetDevice(e->device));
+  const bool gauss = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN;
+  const float thresh = gauss ? 0.0f : bubble_threshold(radius);
+  double reach = radius > 0.0f ? (double)radius / (cb->v.topol == SOMHIP_TOPOL_RECT ? 1.0 : 0.8660254037844386) + 1.0 : 1.0;
+  const int ireach = reach > 1e6 ? 1000000 : (int)reach;
+  const int64_t CH = 4096;
+  void *dk, *dq;
+  CHK(engine_scratch(e, 3, sizeof(uint64_t) * (size_t)std::min(CH, count), &dk));
+  CHK(engine_scratch(e, 4, sizeof(float) * (size_t)std::min(CH, count), &dq));
+  const size_t dyn = (size_t)cb->v.d * 5 + 16;
+  for (int64_t off = 0; off < count; off += CH) {
+    const int64_t c = std::min(CH, count - off);
+    const int64_t f = (first + off) % ds->n;
+    CHK(scan_keys_top1(cb, ds, f, c, (uint64_t *)dk));
+    if (gauss)
+      hipLaunchKernelGGL(k_qerror2<true>, dim3((unsigned)c), dim3(256), dyn, e->stream, cb->v, cb->ydim, ds->d_rows,
+                         ds->d_mask, ds->n, f, (const uint64_t *)dk, radius, thresh, ireach, (float *)dq);
+    else
+      hipLaunchKernelGGL(k_qerror2<false>, dim3((unsigned)c), dim3(256), dyn, e->stream, cb->v, cb->ydim, ds->d_rows,
+                         ds->d_mask, ds->n, f, (const uint64_t *)dk, radius, thresh, ireach, (float *)dq);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out + off, dq, sizeof(float) * (size_t)c, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (ret)
+      for (int64_t i = 0; i < c; i++) {
+        const int64_t r = (f + i) % ds->n;
+        ret[off + i] = (!ds->all_masked.empty() && ds->all_masked[(size_t)r]) ? 0 : 1;
+      }
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------
 // som_training
 // ---------------------------------------------------------------------------------

@@ -239,3 +239,18 @@ def qerror_sum(diff, ret=None):
             continue
         q = np.float32(np.float64(q) + np.sqrt(np.float64(d[i])))
     return q
+
+
+def qerror2_sum(cb, ds, radius, first=0, count=None):
+    """find_qerror2 (reference som_rout.c:823-885): per-sample neighbourhood-weighted errors from
+    the GPU, added in data order into a float32 accumulator like the reference's."""
+    n = ds.n if count is None else count
+    out = np.zeros(n, dtype=np.float32)
+    ret = np.zeros(n, dtype=np.int32)
+    check(cb.e.lib.somhip_qerror2(cb.h, ds.h, C.c_float(radius), first, n, _p(out, _lib.c_float_p),
+                                  _p(ret, _lib.c_i32_p)))
+    q = np.float32(0.0)
+    for i in range(n):
+        if ret[i]:
+            q = np.float32(q + out[i])
+    return q

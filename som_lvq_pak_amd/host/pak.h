@@ -136,6 +136,7 @@ struct entries *olvq1_training(struct teach_params *teach, const char *infile, c
 struct entries *lvq2_training(struct teach_params *teach, float winlen);
 struct entries *lvq3_training(struct teach_params *teach, float epsilon, float winlen);
 float find_qerror(struct teach_params *teach);
+float find_qerror2(struct teach_params *teach);   /* qerror -qetype 1 (som_rout.c:823) */
 /* winners of every data row (the scan behind compute_accuracy / find_labels) */
 int find_all_winners(struct teach_params *teach, int32_t *index, float *diff, int32_t *ret);
 void pak_shutdown(void);

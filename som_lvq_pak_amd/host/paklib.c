@@ -652,3 +652,28 @@ float find_qerror(struct teach_params *teach)                 /* som_rout.c:678-
   free(idx); free(ret); free(diff);
   return qerror;
 }
+
+float find_qerror2(struct teach_params *teach)                /* som_rout.c:823-885 */
+{
+  if (set_som_params(teach)) { fprintf(stderr, "find_qerror2: can't set SOM parameters\n"); return -1; }
+  long n = teach->data->num_entries;
+  if (n <= 0) { fprintf(stderr, "find_qerror2: can't get data\n"); return -1.0f; }
+  ifverbose(3) fprintf(stderr, "qmode 1, %s neighbourhood\n", teach->codes->neigh == NEIGH_GAUSSIAN ? "gaussian" : "bubble");
+  float *q = malloc(sizeof(float) * n);
+  int32_t *ret = malloc(sizeof(int32_t) * n);
+  somhip_codebook *cb = mirror_codes(teach->codes, 0);
+  somhip_dataset *ds = mirror_data(teach->data, 0);
+  float qerror = -1.0f;
+  if (cb && ds) {
+    if (somhip_qerror2(cb, ds, teach->radius, 0, n, q, ret)) fprintf(stderr, "%s\n", somhip_last_error());
+    else {
+      qerror = 0.0f;
+      for (long i = 0; i < n; i++)
+        if (ret[i]) qerror += q[i];                           /* ignore empty vectors, :858; float sum :864 */
+    }
+  }
+  if (cb) somhip_codebook_destroy(cb);
+  if (ds) somhip_dataset_destroy(ds);
+  free(q); free(ret);
+  return qerror;
+}

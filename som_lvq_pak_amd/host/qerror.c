@@ -6,7 +6,9 @@
 
 static const char *usage =
     "qerror - quantization error of a map (MI355X engine)\n"
-    "Required:  -cin file  -din file\nOptional:  -buffer N  -selfuncs hip  -v level\n";
+    "Required:  -cin file  -din file\n"
+    "Optional:  -qetype 1 (neighbourhood-weighted error)  -radius r (for -qetype 1, default 1.0)\n"
+    "           -buffer N  -selfuncs hip  -v level\n";
 
 int main(int argc, char **argv)
 {
@@ -18,7 +20,7 @@ int main(int argc, char **argv)
   char *in_code_file = extract_parameter(argc, argv, "-cin", ALWAYS);
   char *funcname = extract_parameter(argc, argv, "-selfuncs", OPTION);
   int qmode = (int)oatoi(extract_parameter(argc, argv, "-qetype", OPTION), 0);
-  if (qmode > 0) { fprintf(stderr, "qerror: -qetype %d is not supported by this engine\n", qmode); exit(1); }
+  teach.radius = oatof(extract_parameter(argc, argv, "-radius", OPTION), 1.0f);
 
   ifverbose(2) fprintf(stderr, "Input entries are read from file %s\n", in_data_file);
   struct entries *data = open_entries(in_data_file, 0, 1);
@@ -36,7 +38,7 @@ int main(int argc, char **argv)
   }
   set_teach_params(&teach, codes, data, funcname);
   set_som_params(&teach);
-  float qerror = find_qerror(&teach);
+  float qerror = qmode > 0 ? find_qerror2(&teach) : find_qerror(&teach);
   long nod = data->num_entries;
   ifverbose(1)
     fprintf(stdout, "Quantization error of %s with map %s is %f per sample (%ld samples)\n",

@@ -75,6 +75,14 @@ def test_vsom_and_qerror_match_reference_cli(tools, tmp_path, tag):
 
 
 @pytest.mark.gpu
+def test_qerror_qetype1_matches_reference_cli(tools):
+    """qerror -qetype 1 -radius 2 on the reference's own map (find_qerror2, som_rout.c:823)"""
+    p = run("qerror", "-din", os.path.join(DATA, "ex.dat"), "-cin", os.path.join(CLI, "som_hexa_bubble.cod"),
+            "-qetype", 1, "-radius", 2, "-v", 0)
+    assert p.stdout == EXPECTED["som"]["qerror2_r2"]
+
+
+@pytest.mark.gpu
 def test_vsom_variants(tools, tmp_path):
     d, init = os.path.join(DATA, "ex.dat"), os.path.join(CLI, "som_init_hexa_bubble.cod")
     out = tmp_path / "o.cod"

@@ -114,6 +114,36 @@ def test_qerror_golden(eng, E, exdata):
     assert "%f" % float(E.qerror_sum(gd2, gr2) / np.float32(3840)) == "3.571006"
 
 
+def test_qerror2_golden(eng, E, exdata):
+    """qerror -qetype 1 = find_qerror2 (som_rout.c:823): values the real reference produced."""
+    g = load_trace("som_qerror2")
+    ds = E.Dataset(eng, exdata["ex"].points)
+    hb, hg = read_cod("som_hexa_bubble.cod"), read_cod("som_hexa_gaussian.cod")
+    cb = E.Codebook(eng, hb.points, E.TOPOL_HEXA, E.NEIGH_BUBBLE, 12, 8)
+    assert E.qerror2_sum(cb, ds, 2.0) == g["bubble_r2"]
+    cg = E.Codebook(eng, hg.points, E.TOPOL_HEXA, E.NEIGH_GAUSSIAN, 12, 8)
+    assert E.qerror2_sum(cg, ds, 2.0) == g["gaussian_r2"]
+
+
+@pytest.mark.parametrize("xdim,ydim,d,topol,neigh,radius", [
+    (7, 5, 6, 3, 1, 2.5), (7, 5, 6, 4, 2, 1.7), (16, 8, 9, 3, 1, 3.0),      # 16x8: 8x8-patch storage order
+    (24, 16, 33, 3, 2, 4.2), (40, 24, 5, 4, 1, 6.0), (9, 30, 4, 3, 1, 0.0), (5, 4, 3, 4, 1, 100.0)])
+def test_qerror2_random_vs_oracle(eng, E, oracle, xdim, ydim, d, topol, neigh, radius):
+    """bubble and gaussian, both lattices, masked samples, radius 0 and radius > map: the
+    per-sample sums are fp32 sums in unit order, so the totals must agree bit for bit."""
+    x, _ = synth(70 + xdim, 150, d)
+    rs = np.random.RandomState(xdim * ydim)
+    codes = (x[rs.randint(0, 150, xdim * ydim)] + rs.standard_normal((xdim * ydim, d))).astype(np.float32)
+    mask = (rs.random_sample(x.shape) < 0.15).astype(np.uint8)
+    mask[5] = 1                                               # one sample entirely masked: skipped
+    want = np.float32(oracle.find_qerror2(codes, xdim, topol, neigh, x, radius, mask=mask))
+    cb = E.Codebook(eng, codes, topol, neigh, xdim, ydim)
+    ds = E.Dataset(eng, x, mask=mask)
+    assert bits(E.qerror2_sum(cb, ds, radius)) == bits(want)
+    want2 = np.float32(oracle.find_qerror2(codes, xdim, topol, neigh, x, radius))
+    assert bits(E.qerror2_sum(cb, E.Dataset(eng, x), radius)) == bits(want2)
+
+
 # --------------------------------------------------------------------------- som_training, online
 TOPOL = {"hexa": 3, "rect": 4}
 NEIGH = {"bubble": 1, "gaussian": 2}
