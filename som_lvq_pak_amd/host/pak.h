@@ -139,6 +139,10 @@ float find_qerror(struct teach_params *teach);
 float find_qerror2(struct teach_params *teach);   /* qerror -qetype 1 (som_rout.c:823) */
 /* winners of every data row (the scan behind compute_accuracy / find_labels) */
 int find_all_winners(struct teach_params *teach, int32_t *index, float *diff, int32_t *ret);
+/* k-NN consumers (eveninit/propinit, knntest, classify): k <= 8 */
+int find_all_knn(struct entries *codes, struct entries *data, int knn, int32_t *index, float *diff);
+unsigned char *knn_correct_all(struct entries *data, int knn);
+struct entries *pick_rows(struct entries *src, const long *rows, long n);
 void pak_shutdown(void);
 
 #endif

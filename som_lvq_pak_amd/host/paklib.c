@@ -635,6 +635,73 @@ int find_all_winners(struct teach_params *teach, int32_t *index, float *diff, in
   return rc;
 }
 
+/* k nearest codes of every data row (find_winner_knn, lvq_pak.c:152-221; knn = 1 is
+ * find_winner_euc): index/diff [n][knn], nearest first, ties in the reference's order. */
+int find_all_knn(struct entries *codes, struct entries *data, int knn, int32_t *index, float *diff)
+{
+  if (knn < 1) knn = 1;
+  if (knn > 8) { fprintf(stderr, "this engine finds at most 8 nearest neighbours (-knn %d)\n", knn); return 1; }
+  somhip_codebook *cb = mirror_codes(codes, 0);
+  somhip_dataset *ds = mirror_data(data, 0);
+  int rc = 1;
+  if (cb && ds) {
+    rc = somhip_find_winners(cb, ds, 0, data->num_entries, knn, knn >= 2 ? SOMHIP_TIE_KNN : SOMHIP_TIE_FIRST,
+                             index, diff, NULL);
+    if (rc) fprintf(stderr, "%s\n", somhip_last_error());
+  }
+  if (cb) somhip_codebook_destroy(cb);
+  if (ds) somhip_dataset_destroy(ds);
+  return rc;
+}
+
+/* correct_by_knn (lvq_rout.c:38-78) for every row of `data` against `data` itself: the majority
+ * label (head of the hit list built nearest-first) equals the row's own first label. */
+unsigned char *knn_correct_all(struct entries *data, int knn)
+{
+  long n = data->num_entries;
+  if (knn < 1) knn = 1;
+  int32_t *idx = malloc(sizeof(int32_t) * n * knn);
+  float *diff = malloc(sizeof(float) * n * knn);
+  unsigned char *ok = calloc(n, 1);
+  if (find_all_knn(data, data, knn, idx, diff)) { free(idx); free(diff); free(ok); return NULL; }
+  for (long r = 0; r < n; r++) {
+    struct hitlist *hits = new_hitlist();
+    int found = 1;
+    for (int k = 0; k < knn; k++) {
+      long w = idx[r * knn + k];
+      if (w < 0) { found = 0; break; }
+      add_hit(hits, get_entry_label(&data->rows[w]));
+    }
+    if (!found) { fprintf(stderr, "correct_by_knn: can't find winners\n"); ok[r] = 1; }   /* -1 is "true" at :182 */
+    else ok[r] = hits->entries > 0 && hits->label[0] == get_entry_label(&data->rows[r]);
+    free_hitlist(hits);
+  }
+  free(idx); free(diff);
+  return ok;
+}
+
+/* a new entries block holding copies of the given rows of src (copy_entries + copy_entry,
+ * datafile.c): header fields of src, vectors, masks and all labels */
+struct entries *pick_rows(struct entries *src, const long *rows, long n)
+{
+  struct entries *e = calloc(1, sizeof *e);
+  int dim = src->dimension;
+  e->dimension = src->dimension; e->topol = src->topol; e->neigh = src->neigh;
+  e->xdim = src->xdim; e->ydim = src->ydim; e->num_entries = n;
+  e->points = malloc(sizeof(float) * (n > 0 ? n : 1) * dim);
+  e->rows = calloc(n > 0 ? n : 1, sizeof(struct data_entry));
+  if (src->masks) e->masks = calloc((n > 0 ? n : 1) * dim, 1);
+  for (long k = 0; k < n; k++) {
+    struct data_entry *s = &src->rows[rows[k]], *d = &e->rows[k];
+    d->points = e->points + k * dim;
+    memcpy(d->points, s->points, sizeof(float) * dim);
+    if (e->masks && s->mask) { d->mask = e->masks + k * dim; memcpy(d->mask, s->mask, dim); }
+    for (int l = 0; l < s->num_labs; l++) add_entry_label(e, k, s->labels[l]);
+    d->weight = s->weight;
+  }
+  return e;
+}
+
 float find_qerror(struct teach_params *teach)                 /* som_rout.c:678-731 */
 {
   if (set_som_params(teach)) { fprintf(stderr, "find_qerror: can't set SOM parameters\n"); return -1; }

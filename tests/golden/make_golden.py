@@ -54,7 +54,43 @@ def synth(seed, n, d, k=6, spread=4.0):
     return x.astype(np.float32), which.astype(np.int32) + 1
 
 
+def lvq_tool_goldens(exp, d):
+    """the k-NN consumers around the LVQ loops: propinit / eveninit -knn, knntest, classify"""
+    import tempfile
+    t = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        o = lambda f: os.path.join(tmp, f)  # noqa: E731
+        for tag, tool, args in (("propinit_200", "propinit", ["-noc", 200]),
+                                ("eveninit_knn3_100", "eveninit", ["-noc", 100, "-knn", 3]),
+                                ("propinit_knn1_60", "propinit", ["-noc", 60, "-knn", 1]),
+                                ("eveninit_800", "eveninit", ["-noc", 800])):     # needs the second pass
+            run(tool, "-din", d("ex1.dat"), "-cout", o(tag + ".cod"), *args)
+            t[tag] = {"tool": tool, "args": [str(a) for a in args], "md5": md5(o(tag + ".cod"))}
+        for knn in (1, 3, 5):
+            t["knntest_%d" % knn] = run("knntest", "-din", d("ex2.dat"), "-cin", "lvq_olvq1.cod", "-knn", knn)
+        run("classify", "-din", d("ex2.dat"), "-cin", "lvq_olvq1.cod", "-dout", o("cls.dat"), "-cfout", o("cls.cfo"))
+        t["classify_dout_md5"] = md5(o("cls.dat"))
+        t["classify_cfout_md5"] = md5(o("cls.cfo"))
+        # balance.  The reference never counts the codes it appends (balance.c:188), so its
+        # olvq1_training indexes its learning-rate array past the end for them: most inputs give
+        # results that change with MALLOC_PERTURB_ (or abort in malloc).  These two do not -- the
+        # appended codes only ever win their own sample, which moves nothing.
+        run("eveninit", "-din", d("ex1.dat"), "-cout", o("even400.cod"), "-noc", 400)
+        for tag, cin, args in (("balance_even", os.path.join(CLI, "lvq_init.cod"), []),
+                               ("balance_even400_knn3", o("even400.cod"), ["-knn", 3])):
+            out = run("balance", "-din", d("ex1.dat"), "-cin", cin, "-cout", o(tag + ".cod"), *args)
+            t[tag] = {"args": [str(a) for a in args], "stdout": out, "md5": md5(o(tag + ".cod")),
+                      "lra_md5": md5(o(tag + ".lra"))}
+    exp["lvq"]["tools"] = t
+
+
 def main():
+    if "--lvq-tools" in sys.argv:          # refresh only that section of expected.json
+        build()
+        exp = json.load(open(os.path.join(CLI, "expected.json")))
+        lvq_tool_goldens(exp, lambda f: os.path.join(DATA, f))
+        json.dump(exp, open(os.path.join(CLI, "expected.json"), "w"), indent=1, sort_keys=True)
+        return
     build()
     for p in (DATA, CLI, TR):
         os.makedirs(p, exist_ok=True)
@@ -122,6 +158,7 @@ def main():
         acc = run("accuracy", "-din", d("ex2.dat"), "-cin", out)
         exp["lvq"][tag] = {"tool": tool, "args": [str(a) for a in args], "out": out,
                            "accuracy_stdout": acc, "md5": md5(os.path.join(CLI, out))}
+    lvq_tool_goldens(exp, d)
     json.dump(exp, open(os.path.join(CLI, "expected.json"), "w"), indent=1, sort_keys=True)
 
     # ---------------- in-memory traces through the harness ----------------

@@ -19,7 +19,7 @@ EXPECTED = json.load(open(os.path.join(CLI, "expected.json")))
 
 @pytest.fixture(scope="module")
 def tools():
-    if not os.path.exists(os.path.join(BIN, "vsom")):
+    if not all(os.path.exists(os.path.join(BIN, t)) for t in ("vsom", "knntest", "classify", "eveninit", "propinit", "balance")):
         subprocess.check_call(["make", "-s", "-C", ROOT, "lib"])
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "som_lvq_pak_amd", "host")])
     return BIN
@@ -39,7 +39,8 @@ def md5(path):
 
 # ------------------------------------------------------------------ CPU side
 def test_tools_build_and_usage(tools):
-    for t in ("vsom", "lvqtrain", "qerror", "accuracy", "vcal", "lvq1", "olvq1", "lvq2", "lvq3"):
+    for t in ("vsom", "lvqtrain", "qerror", "accuracy", "vcal", "lvq1", "olvq1", "lvq2", "lvq3",
+              "eveninit", "propinit", "knntest", "classify", "balance"):
         p = run(t, "-help")
         assert "MI355X" in p.stdout
     p = run("qerror", "-din", "x", check=False)          # required flag missing: message + exit(-1)
@@ -131,6 +132,46 @@ def test_lvq_tools_match_reference_cli(tools, tmp_path, tag):
     run("lvqtrain", "-type", ex["tool"], "-din", os.path.join(DATA, "ex1.dat"),
         "-cin", os.path.join(CLI, "lvq_init.cod"), "-cout", out2, *ex["args"], "-v", 0)
     assert md5(out2) == ex["md5"]
+
+
+@pytest.mark.gpu
+def test_lvq_init_knntest_classify_match_reference_cli(tools, tmp_path):
+    """the k-NN consumers around the LVQ loops, byte for byte: eveninit / propinit (k-NN vote of
+    every entry over the whole data set, second picking pass included), knntest, classify"""
+    t = EXPECTED["lvq"]["tools"]
+    out = tmp_path / "init.cod"
+    run("eveninit", "-din", os.path.join(DATA, "ex1.dat"), "-cout", out, "-noc", 200, "-v", 0)
+    assert md5(out) == EXPECTED["lvq"]["init_md5"]
+    for tag in ("propinit_200", "eveninit_knn3_100", "propinit_knn1_60", "eveninit_800"):
+        run(t[tag]["tool"], "-din", os.path.join(DATA, "ex1.dat"), "-cout", out, *t[tag]["args"], "-v", 0)
+        assert md5(out) == t[tag]["md5"], tag
+    run("initlvq", "-type", "propinit", "-din", os.path.join(DATA, "ex1.dat"), "-cout", out, "-noc", 200, "-v", 0)
+    assert md5(out) == t["propinit_200"]["md5"]
+    cod = os.path.join(CLI, "lvq_olvq1.cod")
+    for knn in (1, 3, 5):
+        p = run("knntest", "-din", os.path.join(DATA, "ex2.dat"), "-cin", cod, "-knn", knn, "-v", 0)
+        assert p.stdout == t["knntest_%d" % knn]
+    run("classify", "-din", os.path.join(DATA, "ex2.dat"), "-cin", cod, "-dout", tmp_path / "cls.dat",
+        "-cfout", tmp_path / "cls.cfo", "-v", 0)
+    assert md5(tmp_path / "cls.dat") == t["classify_dout_md5"]
+    assert md5(tmp_path / "cls.cfo") == t["classify_cfout_md5"]
+    p = run("knntest", "-din", os.path.join(DATA, "ex2.dat"), "-cin", cod, "-knn", 9, check=False)
+    assert p.returncode == 1 and "at most 8" in p.stderr
+
+
+@pytest.mark.gpu
+def test_balance_matches_reference_cli(tools, tmp_path):
+    """balance (balance.c:44-226): medians, removal, k-NN picking, one OLVQ1 pass -- codebook, .lra
+    and the printed class table byte for byte"""
+    t = EXPECTED["lvq"]["tools"]
+    e400 = tmp_path / "even400.cod"
+    run("eveninit", "-din", os.path.join(DATA, "ex1.dat"), "-cout", e400, "-noc", 400, "-v", 0)
+    for tag, cin in (("balance_even", os.path.join(CLI, "lvq_init.cod")), ("balance_even400_knn3", e400)):
+        out = tmp_path / (tag + ".cod")
+        p = run("balance", "-din", os.path.join(DATA, "ex1.dat"), "-cin", cin, "-cout", out, *t[tag]["args"], "-v", 0)
+        assert p.stdout == t[tag]["stdout"], tag
+        assert md5(out) == t[tag]["md5"], tag
+        assert md5(tmp_path / (tag + ".lra")) == t[tag]["lra_md5"], tag
 
 
 @pytest.mark.gpu
