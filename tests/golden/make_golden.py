@@ -71,6 +71,15 @@ def lvq_tool_goldens(exp, d):
         run("classify", "-din", d("ex2.dat"), "-cin", "lvq_olvq1.cod", "-dout", o("cls.dat"), "-cfout", o("cls.cfo"))
         t["classify_dout_md5"] = md5(o("cls.dat"))
         t["classify_cfout_md5"] = md5(o("cls.cfo"))
+        # cmatr, setlabel (codes relabelled by their 3 and 5 nearest data vectors), elimin
+        t["cmatr"] = run("cmatr", "-din", d("ex2.dat"), "-cin", "lvq_olvq1.cod", "-cfout", o("cm.cfo"))
+        t["cmatr_cfout_md5"] = md5(o("cm.cfo"))
+        for knn in (3, 5):
+            run("setlabel", "-din", d("ex2.dat"), "-cin", "lvq_olvq1.cod", "-cout", o("sl.cod"), "-knn", knn)
+            t["setlabel_%d_md5" % knn] = md5(o("sl.cod"))
+        for knn in (3, 5, 8):
+            run("elimin", "-din", d("ex1.dat"), "-cout", o("el.cod"), "-knn", knn)
+            t["elimin_%d_md5" % knn] = md5(o("el.cod"))
         # balance.  The reference never counts the codes it appends (balance.c:188), so its
         # olvq1_training indexes its learning-rate array past the end for them: most inputs give
         # results that change with MALLOC_PERTURB_ (or abort in malloc).  These two do not -- the

@@ -19,7 +19,7 @@ EXPECTED = json.load(open(os.path.join(CLI, "expected.json")))
 
 @pytest.fixture(scope="module")
 def tools():
-    if not all(os.path.exists(os.path.join(BIN, t)) for t in ("vsom", "knntest", "classify", "eveninit", "propinit", "balance")):
+    if not all(os.path.exists(os.path.join(BIN, t)) for t in ("vsom", "knntest", "classify", "eveninit", "propinit", "balance", "cmatr", "setlabel", "elimin")):
         subprocess.check_call(["make", "-s", "-C", ROOT, "lib"])
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "som_lvq_pak_amd", "host")])
     return BIN
@@ -40,7 +40,7 @@ def md5(path):
 # ------------------------------------------------------------------ CPU side
 def test_tools_build_and_usage(tools):
     for t in ("vsom", "lvqtrain", "qerror", "accuracy", "vcal", "lvq1", "olvq1", "lvq2", "lvq3",
-              "eveninit", "propinit", "knntest", "classify", "balance"):
+              "eveninit", "propinit", "knntest", "classify", "balance", "cmatr", "setlabel", "elimin"):
         p = run(t, "-help")
         assert "MI355X" in p.stdout
     p = run("qerror", "-din", "x", check=False)          # required flag missing: message + exit(-1)
@@ -157,6 +157,21 @@ def test_lvq_init_knntest_classify_match_reference_cli(tools, tmp_path):
     assert md5(tmp_path / "cls.cfo") == t["classify_cfout_md5"]
     p = run("knntest", "-din", os.path.join(DATA, "ex2.dat"), "-cin", cod, "-knn", 9, check=False)
     assert p.returncode == 1 and "at most 8" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cmatr_setlabel_elimin_match_reference_cli(tools, tmp_path):
+    t = EXPECTED["lvq"]["tools"]
+    cod = os.path.join(CLI, "lvq_olvq1.cod")
+    p = run("cmatr", "-din", os.path.join(DATA, "ex2.dat"), "-cin", cod, "-cfout", tmp_path / "cm.cfo", "-v", 0)
+    assert p.stdout == t["cmatr"]
+    assert md5(tmp_path / "cm.cfo") == t["cmatr_cfout_md5"]
+    for knn in (3, 5):
+        run("setlabel", "-din", os.path.join(DATA, "ex2.dat"), "-cin", cod, "-cout", tmp_path / "sl.cod", "-knn", knn, "-v", 0)
+        assert md5(tmp_path / "sl.cod") == t["setlabel_%d_md5" % knn], knn
+    for knn in (3, 5, 8):
+        run("elimin", "-din", os.path.join(DATA, "ex1.dat"), "-cout", tmp_path / "el.cod", "-knn", knn, "-v", 0)
+        assert md5(tmp_path / "el.cod") == t["elimin_%d_md5" % knn], knn
 
 
 @pytest.mark.gpu
