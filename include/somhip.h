@@ -174,7 +174,9 @@ int  somhip_qerror2(somhip_codebook *cb, somhip_dataset *ds, float radius, int64
  * keys: DEVICE array [count] of uint64 = (fp32 bits of squared distance << 32) |
  * global row index.  All distances are >= 0, so unsigned order == (distance, index)
  * order and an element-wise MIN across shards is exactly find_winner_euc over the
- * whole codebook, lowest index winning ties (lvq_pak.c:79). */
+ * whole codebook, lowest index winning ties (lvq_pak.c:79).  "No winner in this shard"
+ * is 0x7FFFFFFFFFFFFFFF, so every key is non-negative as int64 and a SIGNED 64-bit MIN
+ * (all that torch.distributed / RCCL offer) orders them the same way. */
 int  somhip_batch_winner_keys(somhip_codebook *cb, somhip_dataset *ds, int64_t first,
                               int64_t count, uint64_t *dev_keys);
 int  somhip_som_batch_update(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,

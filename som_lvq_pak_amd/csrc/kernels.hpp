@@ -2031,6 +2031,13 @@ __global__ __launch_bounds__(256) void k_qerror2(CbView cb, int ydim, const floa
   if (tid == 0) out[smp] = q;
 }
 
+// keys handed to a host-side collective: signed 64-bit MIN must order them like unsigned MIN, so
+// the all-ones "no winner" key becomes INT64_MAX (still >= FLT_MAX in its distance half)
+__global__ void k_clamp_keys(uint64_t *__restrict__ keys, int64_t n) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n && (keys[i] >> 63)) keys[i] = 0x7FFFFFFFFFFFFFFFull;
+}
+
 __global__ void k_fill_u64(uint64_t *p, int64_t n, uint64_t v) {
   int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

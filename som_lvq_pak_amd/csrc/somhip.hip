@@ -668,7 +668,10 @@ extern "C" int somhip_batch_winner_keys(somhip_codebook *cb, somhip_dataset *ds,
   CHK(check_pair(cb, ds, "somhip_batch_winner_keys"));
   if (count <= 0) return 0;
   HIPCHK(hipSetDevice(cb->e->device));
-  return scan_keys_top1(cb, ds, first, count, dev_keys);
+  CHK(scan_keys_top1(cb, ds, first, count, dev_keys));
+  hipLaunchKernelGGL(k_clamp_keys, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, cb->e->stream, dev_keys, count);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 static void decode_key(uint64_t k, bool inverted, int32_t *index, float *diff) {

@@ -42,11 +42,13 @@ def unpack_keys(keys):
     return diff, index
 
 
-def allreduce_min_keys(keys, group=None):
-    """In-place global MIN of packed keys held in an int64 torch tensor (any device)."""
+def allreduce_min_keys(keys, group=None, nonnegative=False):
+    """In-place global MIN of packed keys held in an int64 torch tensor (any device).
+    nonnegative=True: the producer already mapped the all-ones key (somhip_batch_winner_keys does)."""
     import torch
     import torch.distributed as dist
-    keys.copy_(torch.where(keys < 0, torch.full_like(keys, KEY_MAX_I64), keys))
+    if not nonnegative:
+        keys.copy_(torch.where(keys < 0, torch.full_like(keys, KEY_MAX_I64), keys))
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         if keys.is_cuda and dist.get_backend(group) == "gloo":     # rehearsal path: stage through the host
             host = keys.cpu()
@@ -75,7 +77,7 @@ class ShardedSom:
     def step(self, it0, data_first, count):
         keys = self.shard.winner_keys(data_first, count)
         with self.shard.collective_scope():
-            allreduce_min_keys(keys)
+            allreduce_min_keys(keys, nonnegative=getattr(self.shard, "keys_nonnegative", False))
         self.shard.update(it0, count, data_first, keys)
         return keys
 
@@ -97,6 +99,8 @@ class GpuShard:
     """The local half on an MI355X, through the C ABI (somhip_batch_winner_keys /
     somhip_som_batch_update).  `keys` is a torch int64 tensor on the same device whose
     storage the engine writes directly."""
+
+    keys_nonnegative = True          # somhip_batch_winner_keys never returns the all-ones key
 
     def __init__(self, engine, codebook, dataset, params_factory, max_batch):
         import torch
