@@ -41,40 +41,11 @@ int main(int argc, char **argv)
   struct entries *data = open_entries(in_data_file, 0, 1);
   if (!data) { fprintf(stderr, "Can't open data file '%s'\n", in_data_file); exit(1); }
   init_random((int)randomize);
-  int dim = data->dimension;
-
-  /* bounding box over unmasked components; the reference seeds its maximum with FLT_MIN
-   * (the smallest positive float), som_rout.c:108-111 */
-  float *hi = malloc(sizeof(float) * dim), *lo = malloc(sizeof(float) * dim);
-  long *cnt = calloc(dim, sizeof(long));
-  for (int i = 0; i < dim; i++) { hi[i] = FLT_MIN; lo[i] = FLT_MAX; }
-  for (long r = 0; r < data->num_entries; r++) {
-    struct data_entry *e = &data->rows[r];
-    for (int i = 0; i < dim; i++)
-      if (!(e->mask && e->mask[i])) {
-        cnt[i]++;
-        if (hi[i] < e->points[i]) hi[i] = e->points[i];
-        if (lo[i] > e->points[i]) lo[i] = e->points[i];
-      }
-  }
-  for (int i = 0; i < dim; i++)
-    if (cnt[i] == 0) fprintf(stderr, "randinit_codes: warning! component %d has no data, using 0.0\n", i + 1);
-
-  struct entries *codes = calloc(1, sizeof *codes);
-  codes->dimension = (short)dim; codes->topol = (short)topol; codes->neigh = (short)neigh;
-  codes->xdim = (short)xdim; codes->ydim = (short)ydim; codes->num_entries = noc;
-  codes->points = malloc(sizeof(float) * noc * dim);
-  codes->rows = calloc(noc, sizeof(struct data_entry));
-  for (long k = 0; k < noc; k++) {
-    codes->rows[k].points = codes->points + k * dim;
-    for (int i = 0; i < dim; i++)                  /* som_rout.c:140-150 */
-      codes->rows[k].points[i] = cnt[i] > 0 ? lo[i] + (hi[i] - lo[i]) * ((float)orand() / 32768.0) : 0.0;
-  }
+  struct entries *codes = randinit_codes(data, topol, neigh, xdim, ydim);
   ifverbose(2) fprintf(stderr, "Codebook entries are saved to file %s\n", out_code_file);
   char comments[256];
   snprintf(comments, sizeof comments, "# random seed: %ld\n", randomize);
   save_entries_wcomments(codes, out_code_file, comments);
   close_entries(data); close_entries(codes);
-  free(hi); free(lo); free(cnt);
   return 0;
 }

@@ -6,6 +6,7 @@
 #define _GNU_SOURCE
 #include "pak.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -633,6 +634,41 @@ int find_all_winners(struct teach_params *teach, int32_t *index, float *diff, in
   if (cb) somhip_codebook_destroy(cb);
   if (ds) somhip_dataset_destroy(ds);
   return rc;
+}
+
+/* randinit_codes (som_rout.c:34-162): every component uniform in the bounding box of the data
+ * (unmasked components only), orand() drawn unit by unit, component by component. */
+struct entries *randinit_codes(struct entries *data, int topol, int neigh, int xdim, int ydim)
+{
+  int dim = data->dimension;
+  long noc = (long)xdim * ydim;
+  /* the reference seeds its maximum with FLT_MIN (the smallest positive float), som_rout.c:108-111 */
+  float *hi = malloc(sizeof(float) * dim), *lo = malloc(sizeof(float) * dim);
+  long *cnt = calloc(dim, sizeof(long));
+  for (int i = 0; i < dim; i++) { hi[i] = FLT_MIN; lo[i] = FLT_MAX; }
+  for (long r = 0; r < data->num_entries; r++) {
+    struct data_entry *e = &data->rows[r];
+    for (int i = 0; i < dim; i++)
+      if (!(e->mask && e->mask[i])) {
+        cnt[i]++;
+        if (hi[i] < e->points[i]) hi[i] = e->points[i];
+        if (lo[i] > e->points[i]) lo[i] = e->points[i];
+      }
+  }
+  for (int i = 0; i < dim; i++)
+    if (cnt[i] == 0) fprintf(stderr, "randinit_codes: warning! component %d has no data, using 0.0\n", i + 1);
+  struct entries *codes = calloc(1, sizeof *codes);
+  codes->dimension = (short)dim; codes->topol = (short)topol; codes->neigh = (short)neigh;
+  codes->xdim = (short)xdim; codes->ydim = (short)ydim; codes->num_entries = noc;
+  codes->points = malloc(sizeof(float) * noc * dim);
+  codes->rows = calloc(noc, sizeof(struct data_entry));
+  for (long k = 0; k < noc; k++) {
+    codes->rows[k].points = codes->points + k * dim;
+    for (int i = 0; i < dim; i++)                  /* som_rout.c:140-150 */
+      codes->rows[k].points[i] = cnt[i] > 0 ? lo[i] + (hi[i] - lo[i]) * ((float)orand() / 32768.0) : 0.0;
+  }
+  free(hi); free(lo); free(cnt);
+  return codes;
 }
 
 /* k nearest codes of every data row (find_winner_knn, lvq_pak.c:152-221; knn = 1 is

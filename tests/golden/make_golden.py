@@ -54,6 +54,25 @@ def synth(seed, n, d, k=6, spread=4.0):
     return x.astype(np.float32), which.astype(np.int32) + 1
 
 
+VFIND_ANSWERS = ["3", "{data}", "{data}", "{out}", "hexa", "bubble", "6", "5", "800", "0.05", "5", "2000", "0.02", "2"]
+
+
+def vfind_golden(exp, d):
+    """vfind: 3 trials of randinit -> vsom -> vsom -> qerror, best map kept (answers on stdin)"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        res = {}
+        for tag, extra in (("q0", []), ("q1", ["-qetype", "1"])):
+            out = os.path.join(tmp, tag + ".cod")
+            ans = "\n".join(a.format(data=d("ex.dat"), out=out) for a in VFIND_ANSWERS) + "\n"
+            p = subprocess.run([ref_tool("vfind")] + extra, input=ans, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               text=True, cwd=CLI)
+            assert p.returncode == 0, p.stderr
+            res[tag] = {"args": extra, "md5": md5(out), "trials_stderr": [l for l in p.stderr.splitlines() if ": " in l and l.strip()[0].isdigit()],
+                        "last_stdout_line": p.stdout.strip().splitlines()[-1]}
+        exp["som"]["vfind"] = res
+
+
 def lvq_tool_goldens(exp, d):
     """the k-NN consumers around the LVQ loops: propinit / eveninit -knn, knntest, classify"""
     import tempfile
@@ -98,6 +117,7 @@ def main():
         build()
         exp = json.load(open(os.path.join(CLI, "expected.json")))
         lvq_tool_goldens(exp, lambda f: os.path.join(DATA, f))
+        vfind_golden(exp, lambda f: os.path.join(DATA, f))
         json.dump(exp, open(os.path.join(CLI, "expected.json"), "w"), indent=1, sort_keys=True)
         return
     build()
@@ -168,6 +188,7 @@ def main():
         exp["lvq"][tag] = {"tool": tool, "args": [str(a) for a in args], "out": out,
                            "accuracy_stdout": acc, "md5": md5(os.path.join(CLI, out))}
     lvq_tool_goldens(exp, d)
+    vfind_golden(exp, d)
     json.dump(exp, open(os.path.join(CLI, "expected.json"), "w"), indent=1, sort_keys=True)
 
     # ---------------- in-memory traces through the harness ----------------

@@ -19,7 +19,7 @@ EXPECTED = json.load(open(os.path.join(CLI, "expected.json")))
 
 @pytest.fixture(scope="module")
 def tools():
-    if not all(os.path.exists(os.path.join(BIN, t)) for t in ("vsom", "knntest", "classify", "eveninit", "propinit", "balance", "cmatr", "setlabel", "elimin")):
+    if not all(os.path.exists(os.path.join(BIN, t)) for t in ("vsom", "knntest", "classify", "eveninit", "propinit", "balance", "cmatr", "setlabel", "elimin", "vfind")):
         subprocess.check_call(["make", "-s", "-C", ROOT, "lib"])
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "som_lvq_pak_amd", "host")])
     return BIN
@@ -73,6 +73,23 @@ def test_vsom_and_qerror_match_reference_cli(tools, tmp_path, tag):
     assert md5(out) == ex["md5"]
     p = run("qerror", "-din", os.path.join(DATA, "ex.dat"), "-cin", out, "-v", 0)
     assert p.stdout == ex["qerror_stdout"]
+
+
+@pytest.mark.gpu
+def test_vfind_matches_reference_cli(tools, tmp_path):
+    """vfind.c:244-306: three trials (seeds 3, 2, 1) of randinit -> two som_training runs -> qerror
+    (or -qetype 1); per-trial errors, the winning seed and the saved map must equal the reference's"""
+    answers = ["3", "{data}", "{data}", "{out}", "hexa", "bubble", "6", "5", "800", "0.05", "5", "2000", "0.02", "2"]
+    for tag, ex in EXPECTED["som"]["vfind"].items():
+        out = tmp_path / (tag + ".cod")
+        ans = "\n".join(a.format(data=os.path.join(DATA, "ex.dat"), out=out) for a in answers) + "\n"
+        p = subprocess.run([os.path.join(BIN, "vfind")] + ex["args"], input=ans, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True)
+        assert p.returncode == 0, p.stderr
+        trials = [ln for ln in p.stderr.splitlines() if ": " in ln and ln.strip()[:1].isdigit()]
+        assert trials == ex["trials_stderr"], tag
+        assert p.stdout.strip().splitlines()[-1] == ex["last_stdout_line"], tag
+        assert md5(out) == ex["md5"], tag
 
 
 @pytest.mark.gpu
