@@ -161,6 +161,14 @@ int  somhip_lvq_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_lvq_
  * its phases (inputs, cached-row distances, decision, correction) */
 int  somhip_lvq_stats(somhip_engine *e, uint64_t out[8]);
 
+/* ---- lininit's data passes (find_eigenvectors, som_rout.c:211-289) ----------------
+ * sum[i] / count[i]: fp32 sum and number of the unmasked values of component i over all rows in
+ * order (:243-254).  r[i*dim + j], j >= i: fp32 sum over the rows, in order, of
+ * (x_i - mean_i) * (x_j - mean_j) for rows where neither component is masked (:266-284);
+ * elements with j < i are left 0.  The eigenvector iteration itself is O(dim^2) host work. */
+int  somhip_column_sums(somhip_dataset *ds, float *sum, int64_t *count);
+int  somhip_centered_products(somhip_dataset *ds, const float *mean, float *r);
+
 /* ---- find_qerror2 (som_rout.c:823-885; bubble_qerror :734-772, gaussian_qerror :775-818):
  * out[i] = sum over the neighbourhood of sample first+i's winner of (h *) d*d, d =
  * vector_dist_euc (lvq_pak.c:291-316), accumulated in fp32 in unit order exactly as the

@@ -2031,6 +2031,67 @@ __global__ __launch_bounds__(256) void k_qerror2(CbView cb, int ydim, const floa
   if (tid == 0) out[smp] = q;
 }
 
+// =====================================================================================
+// K8: the two data passes of lininit's find_eigenvectors (som_rout.c:211-289), exactly:
+//   column sums    m[i]   += x[r][i]                       over unmasked components, rows in order
+//   centred sums   R[i][j] += (x[r][i] - m[i]) * (x[r][j] - m[j])   for j >= i, rows in order
+// Every output element is its own fp32 chain over the rows, so elements are the parallel axis
+// (131 328 chains at dim 512) and nothing is re-associated.  K8b: a workgroup owns a 16x16
+// block of (i, j); 64 rows at a time are centred once (x - m, one rounding, as the reference
+// forms it) into LDS, then each thread runs mul + add down the 64 rows of its pair.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_column_sums(const float *__restrict__ rows, const uint8_t *__restrict__ mask,
+                                                     int64_t n, int d, float *__restrict__ sum,
+                                                     unsigned long long *__restrict__ cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d) return;
+  float acc = 0.0f;
+  unsigned long long k = 0;
+  for (int64_t r = 0; r < n; r++) {
+    if (!mask || mask[r * d + i] == 0) { acc = acc + rows[r * d + i]; k++; }
+  }
+  sum[i] = acc;
+  cnt[i] = k;
+}
+
+__global__ __launch_bounds__(256) void k_centered_products(const float *__restrict__ rows,
+                                                           const uint8_t *__restrict__ mask, int64_t n, int d,
+                                                           const float *__restrict__ mean, float *__restrict__ R) {
+  constexpr int RB = 64;
+  __shared__ float s_i[RB][16], s_j[RB][16];
+  __shared__ uint8_t s_mi[RB][16], s_mj[RB][16];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj < bi) return;                                   // only j >= i is ever read (som_rout.c:287-289)
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  const int i = bi * 16 + ti, j = bj * 16 + tj;
+  float acc = 0.0f;
+  for (int64_t r0 = 0; r0 < n; r0 += RB) {
+    // stage 64 rows x (16 i-columns + 16 j-columns), centred
+    for (int e = tid; e < RB * 32; e += 256) {
+      const int rr = e >> 5, cc = e & 31;
+      const int col = cc < 16 ? bi * 16 + cc : bj * 16 + (cc - 16);
+      const int64_t r = r0 + rr;
+      float v = 0.0f;
+      uint8_t mk = 1;
+      if (r < n && col < d) {
+        mk = mask ? mask[r * d + col] : 0;
+        v = rows[r * d + col] - mean[col];
+      }
+      if (cc < 16) { s_i[rr][cc] = v; s_mi[rr][cc] = mk; } else { s_j[rr][cc - 16] = v; s_mj[rr][cc - 16] = mk; }
+    }
+    __syncthreads();
+    const int lim = static_cast<int>(n - r0 < RB ? n - r0 : RB);
+    for (int rr = 0; rr < lim; rr++) {
+      if (s_mi[rr][ti] == 0 && s_mj[rr][tj] == 0) {
+        const float p = s_i[rr][ti] * s_j[rr][tj];
+        acc = acc + p;
+      }
+    }
+    __syncthreads();
+  }
+  if (i < d && j < d && j >= i) R[static_cast<int64_t>(i) * d + j] = acc;
+}
+
 // keys handed to a host-side collective: signed 64-bit MIN must order them like unsigned MIN, so
 // the all-ones "no winner" key becomes INT64_MAX (still >= FLT_MAX in its distance half)
 __global__ void k_clamp_keys(uint64_t *__restrict__ keys, int64_t n) {

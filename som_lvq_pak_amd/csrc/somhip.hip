@@ -724,6 +724,46 @@ extern "C" int somhip_find_winners(somhip_codebook *cb, somhip_dataset *ds, int6
   return 0;
 }
 
+// lininit's data passes (find_eigenvectors, som_rout.c:211-289): per-component sums / counts over the
+// unmasked entries, then the upper triangle (j >= i) of sum_r (x_ri - mean_i)(x_rj - mean_j); every
+// element accumulated over the rows in file order, in fp32, like the reference.
+extern "C" int somhip_column_sums(somhip_dataset *ds, float *sum, int64_t *count) {
+  if (!ds || !sum || !count) return fail("somhip_column_sums: null argument");
+  somhip_engine *e = ds->e;
+  HIPCHK(hipSetDevice(e->device));
+  void *dsum, *dcnt;
+  CHK(engine_scratch(e, 3, sizeof(float) * (size_t)ds->d, &dsum));
+  CHK(engine_scratch(e, 4, sizeof(unsigned long long) * (size_t)ds->d, &dcnt));
+  hipLaunchKernelGGL(k_column_sums, dim3((unsigned)((ds->d + 255) / 256)), dim3(256), 0, e->stream, ds->d_rows,
+                     (const uint8_t *)ds->d_mask, ds->n, ds->d, (float *)dsum, (unsigned long long *)dcnt);
+  HIPCHK(hipGetLastError());
+  std::vector<unsigned long long> hc((size_t)ds->d);
+  HIPCHK(hipMemcpyAsync(sum, dsum, sizeof(float) * (size_t)ds->d, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(hc.data(), dcnt, sizeof(unsigned long long) * (size_t)ds->d, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < ds->d; i++) count[i] = (int64_t)hc[(size_t)i];
+  return 0;
+}
+
+extern "C" int somhip_centered_products(somhip_dataset *ds, const float *mean, float *r) {
+  if (!ds || !mean || !r) return fail("somhip_centered_products: null argument");
+  somhip_engine *e = ds->e;
+  HIPCHK(hipSetDevice(e->device));
+  const size_t dd = (size_t)ds->d * ds->d;
+  void *dmean, *dr;
+  CHK(engine_scratch(e, 3, sizeof(float) * (size_t)ds->d, &dmean));
+  CHK(engine_scratch(e, 4, sizeof(float) * dd, &dr));
+  HIPCHK(hipMemcpyAsync(dmean, mean, sizeof(float) * (size_t)ds->d, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemsetAsync(dr, 0, sizeof(float) * dd, e->stream));
+  const unsigned nb = (unsigned)((ds->d + 15) / 16);
+  hipLaunchKernelGGL(k_centered_products, dim3(nb, nb), dim3(256), 0, e->stream, ds->d_rows,
+                     (const uint8_t *)ds->d_mask, ds->n, ds->d, (const float *)dmean, (float *)dr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(r, dr, sizeof(float) * dd, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
 // find_qerror2 (som_rout.c:823-885): out[i] = the neighbourhood-weighted error of sample first+i
 // (0 where the sample has no winner); the caller adds them in data order, as the reference does.
 extern "C" int somhip_qerror2(somhip_codebook *cb, somhip_dataset *ds, float radius, int64_t first,

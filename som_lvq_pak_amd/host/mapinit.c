@@ -1,7 +1,7 @@
-/* mapinit / randinit -- random initialization of a map codebook in the bounding box of the
- * data (SOM_PAK mapinit.c:53-182 driving randinit_codes som_rout.c:34-162).  Host-only: this
- * is the step before the hot path.  `lininit` (principal-axes initialization) is not part of
- * this engine; the name is recognised and refused. */
+/* mapinit / randinit / lininit -- initial map codebook (SOM_PAK mapinit.c:53-182): random in the
+ * bounding box of the data (randinit_codes som_rout.c:34-162, host only) or laid out on the plane
+ * of the two principal axes (lininit_codes som_rout.c:322-429: the two O(n dim^2) data passes run
+ * on the MI355X engine, see paklib.c). */
 #include <float.h>
 #include <stdlib.h>
 #include <string.h>
@@ -9,9 +9,9 @@
 #include "pak.h"
 
 static const char *usage =
-    "randinit (mapinit -init rand) - random initialization of a SOM codebook\n"
+    "randinit / lininit (mapinit -init rand|lin) - initialization of a SOM codebook (MI355X engine for lin)\n"
     "Required:  -din file  -cout file  -topol hexa|rect  -neigh bubble|gaussian  -xdim N  -ydim N\n"
-    "Optional:  -rand seed  -init rand  -v level\n";
+    "Optional:  -rand seed  -init rand|lin  -v level\n";
 
 int main(int argc, char **argv)
 {
@@ -32,8 +32,7 @@ int main(int argc, char **argv)
   int ydim = (int)oatoi(extract_parameter(argc, argv, "-ydim", ALWAYS), 0);
   s = extract_parameter(argc, argv, "-init", OPTION);
   if (s) { init_lin = strcmp(s, "lin") == 0; init_rand = strcmp(s, "rand") == 0; }
-  if (init_lin) { fprintf(stderr, "lininit is not provided by this engine; use randinit\n"); exit(1); }
-  if (!init_rand) { fprintf(stderr, "Unknown initialization type %s\n", s ? s : progname); exit(1); }
+  if (!init_rand && !init_lin) { fprintf(stderr, "Unknown initialization type %s\n", s ? s : progname); exit(1); }
   long noc = (long)xdim * ydim;
   if (noc <= 0 || xdim < 0) { fprintf(stderr, "Dimensions of map (%d %d) are incorrect\n", xdim, ydim); exit(1); }
 
@@ -41,11 +40,15 @@ int main(int argc, char **argv)
   struct entries *data = open_entries(in_data_file, 0, 1);
   if (!data) { fprintf(stderr, "Can't open data file '%s'\n", in_data_file); exit(1); }
   init_random((int)randomize);
-  struct entries *codes = randinit_codes(data, topol, neigh, xdim, ydim);
+  ifverbose(2) fprintf(stderr, "initializing codes (%s)\n", init_lin ? "linear" : "random");
+  struct entries *codes = init_lin ? lininit_codes(data, topol, neigh, xdim, ydim)
+                                   : randinit_codes(data, topol, neigh, xdim, ydim);
+  if (!codes) { fprintf(stderr, "initialization failure\n"); exit(1); }
   ifverbose(2) fprintf(stderr, "Codebook entries are saved to file %s\n", out_code_file);
   char comments[256];
   snprintf(comments, sizeof comments, "# random seed: %ld\n", randomize);
   save_entries_wcomments(codes, out_code_file, comments);
   close_entries(data); close_entries(codes);
+  pak_shutdown();
   return 0;
 }

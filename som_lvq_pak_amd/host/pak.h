@@ -143,6 +143,7 @@ int find_all_winners(struct teach_params *teach, int32_t *index, float *diff, in
 int find_all_knn(struct entries *codes, struct entries *data, int knn, int32_t *index, float *diff);
 unsigned char *knn_correct_all(struct entries *data, int knn);
 struct entries *pick_rows(struct entries *src, const long *rows, long n);
+struct entries *lininit_codes(struct entries *data, int topol, int neigh, int xdim, int ydim);
 struct entries *randinit_codes(struct entries *data, int topol, int neigh, int xdim, int ydim);
 void pak_shutdown(void);
 

@@ -671,6 +671,96 @@ struct entries *randinit_codes(struct entries *data, int topol, int neigh, int x
   return codes;
 }
 
+/* lininit_codes (som_rout.c:322-429) with find_eigenvectors (:211-320): the map is laid out on the
+ * plane spanned by the two principal axes of the data.  The two passes over the data (mean, upper
+ * triangle of the centred product sums -- O(n dim^2)) run on the MI355X engine with the reference's
+ * fp32 accumulation order; the 10-step two-vector power iteration on the dim x dim matrix is host
+ * work, written with the reference's float / double mix so that every rounding falls where it does
+ * there. */
+static void normalize_f(float *v, int n)              /* som_rout.c:166-174 */
+{
+  float sum = 0.0;
+  for (int j = 0; j < n; j++) sum += v[j] * v[j];
+  sum = sqrt(sum);
+  for (int j = 0; j < n; j++) v[j] /= sum;
+}
+static float dotprod_f(const float *v, const float *w, int n)     /* :177-184 */
+{
+  float sum = 0.0;
+  for (int j = 0; j < n; j++) sum += v[j] * w[j];
+  return sum;
+}
+static void gram_schmidt_f(float *v, int n, int e)    /* :187-209 */
+{
+  float *w = malloc(sizeof(float) * n * e);
+  for (int i = 0; i < e; i++) {
+    for (int t = 0; t < n; t++) {
+      float sum = v[i * n + t];
+      for (int j = 0; j < i; j++)
+        for (int p = 0; p < n; p++) sum -= w[j * n + t] * w[j * n + p] * v[i * n + p];
+      w[i * n + t] = sum;
+    }
+    normalize_f(w + i * n, n);
+  }
+  memcpy(v, w, sizeof(float) * n * e);
+  free(w);
+}
+
+struct entries *lininit_codes(struct entries *data, int topol, int neigh, int xdim, int ydim)
+{
+  int n = data->dimension;
+  long k = data->num_entries, noc = (long)xdim * ydim;
+  float *m = malloc(sizeof(float) * n), *r = malloc(sizeof(float) * n * n);
+  float *u = malloc(sizeof(float) * 2 * n), *v = malloc(sizeof(float) * 2 * n);
+  int64_t *k2 = malloc(sizeof(int64_t) * n);
+  float mu[2];
+  struct entries *codes = NULL;
+  somhip_dataset *ds = mirror_data(data, 0);
+  if (!ds) goto fail;
+  if (somhip_column_sums(ds, m, k2)) { fprintf(stderr, "%s\n", somhip_last_error()); goto fail; }
+  if (k < 3) goto fail;                                 /* :256 */
+  for (int i = 0; i < n; i++) m[i] /= k2[i];
+  if (somhip_centered_products(ds, m, r)) { fprintf(stderr, "%s\n", somhip_last_error()); goto fail; }
+  for (int i = 0; i < n; i++)
+    for (int j = i; j < n; j++) r[j * n + i] = r[i * n + j] /= k;
+  for (int i = 0; i < 2; i++) {
+    for (int j = 0; j < n; j++) u[i * n + j] = orand() / 16384.0 - 1.0;
+    normalize_f(u + i * n, n);
+    mu[i] = 1.0;
+  }
+  for (int it = 0; it < 10; it++) {
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < n; j++) v[i * n + j] = mu[i] * dotprod_f(r + j * n, u + i * n, n) + u[i * n + j];
+    gram_schmidt_f(v, n, 2);
+    float sum = 0.0;                                    /* not reset between the two vectors (:300-306) */
+    for (int i = 0; i < 2; i++) {
+      for (int j = 0; j < n; j++) sum += fabs(v[i * n + j] / dotprod_f(r + j * n, v + i * n, n));
+      mu[i] = sum / n;
+    }
+    memcpy(u, v, sizeof(float) * 2 * n);
+  }
+  if (mu[0] == 0.0 || mu[1] == 0.0) goto fail;
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < n; j++) u[i * n + j] /= sqrt(mu[i]);
+
+  codes = calloc(1, sizeof *codes);
+  codes->dimension = (short)n; codes->topol = (short)topol; codes->neigh = (short)neigh;
+  codes->xdim = (short)xdim; codes->ydim = (short)ydim; codes->num_entries = noc;
+  codes->points = malloc(sizeof(float) * noc * n);
+  codes->rows = calloc(noc, sizeof(struct data_entry));
+  for (long index = 0; index < noc; index++) {          /* :405-421 */
+    float xf = 4.0 * (float)(index % xdim) / (xdim - 1.0) - 2.0;
+    float yf = 4.0 * (float)(index / xdim) / (ydim - 1.0) - 2.0;
+    float *pt = codes->rows[index].points = codes->points + index * n;
+    for (int i = 0; i < n; i++) pt[i] = m[i] + xf * u[i] + yf * u[n + i];
+  }
+fail:
+  if (!codes) fprintf(stderr, "lininit_codes: Can't find eigenvectors\n");
+  if (ds) somhip_dataset_destroy(ds);
+  free(m); free(r); free(u); free(v); free(k2);
+  return codes;
+}
+
 /* k nearest codes of every data row (find_winner_knn, lvq_pak.c:152-221; knn = 1 is
  * find_winner_euc): index/diff [n][knn], nearest first, ties in the reference's order. */
 int find_all_knn(struct entries *codes, struct entries *data, int knn, int32_t *index, float *diff)

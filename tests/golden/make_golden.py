@@ -73,6 +73,27 @@ def vfind_golden(exp, d):
         exp["som"]["vfind"] = res
 
 
+def lininit_golden(exp, d):
+    """lininit on ex.dat and on a copy of its first 500 rows with every 7th value masked ('x')"""
+    import tempfile
+    lines = open(d("ex.dat")).read().splitlines()
+    rs = np.random.RandomState(99)
+    out_lines = [lines[0]]
+    for ln in lines[1:501]:
+        toks = ln.split()
+        out_lines.append(" ".join("x" if rs.random_sample() < 0.14 else t for t in toks))
+    open(d("ex_masked.dat"), "w").write("\n".join(out_lines) + "\n")
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, data, args in (("ex_hexa", "ex.dat", ["-xdim", 12, "-ydim", 8, "-topol", "hexa", "-neigh", "bubble", "-rand", 123]),
+                                ("ex_rect_seed5", "ex.dat", ["-xdim", 7, "-ydim", 9, "-topol", "rect", "-neigh", "gaussian", "-rand", 5]),
+                                ("masked", "ex_masked.dat", ["-xdim", 10, "-ydim", 6, "-topol", "hexa", "-neigh", "bubble", "-rand", 11])):
+            out = os.path.join(tmp, tag + ".cod")
+            run("lininit", "-din", d(data), "-cout", out, *args)
+            res[tag] = {"data": data, "args": [str(a) for a in args], "md5": md5(out)}
+    exp["som"]["lininit"] = res
+
+
 def lvq_tool_goldens(exp, d):
     """the k-NN consumers around the LVQ loops: propinit / eveninit -knn, knntest, classify"""
     import tempfile
@@ -118,6 +139,7 @@ def main():
         exp = json.load(open(os.path.join(CLI, "expected.json")))
         lvq_tool_goldens(exp, lambda f: os.path.join(DATA, f))
         vfind_golden(exp, lambda f: os.path.join(DATA, f))
+        lininit_golden(exp, lambda f: os.path.join(DATA, f))
         json.dump(exp, open(os.path.join(CLI, "expected.json"), "w"), indent=1, sort_keys=True)
         return
     build()
@@ -189,6 +211,7 @@ def main():
                            "accuracy_stdout": acc, "md5": md5(os.path.join(CLI, out))}
     lvq_tool_goldens(exp, d)
     vfind_golden(exp, d)
+    lininit_golden(exp, d)
     json.dump(exp, open(os.path.join(CLI, "expected.json"), "w"), indent=1, sort_keys=True)
 
     # ---------------- in-memory traces through the harness ----------------

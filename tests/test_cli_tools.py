@@ -246,9 +246,20 @@ def test_randinit_matches_reference(tools, tmp_path):
     run("randinit", "-din", os.path.join(DATA, "ex.dat"), "-cout", out, "-xdim", 12, "-ydim", 8,
         "-topol", "hexa", "-neigh", "bubble", "-rand", 123, "-v", 0)
     assert md5(out) == EXPECTED["som"]["randinit_md5"]
-    p = run("lininit", "-din", os.path.join(DATA, "ex.dat"), "-cout", out, "-xdim", 12, "-ydim", 8,
-            "-topol", "hexa", "-neigh", "bubble", check=False)
-    assert p.returncode == 1 and "lininit is not provided" in p.stderr
+
+
+@pytest.mark.gpu
+def test_lininit_matches_reference(tools, tmp_path):
+    """lininit_codes (som_rout.c:322): mean and centred product sums from the GPU (fp32, rows in
+    order), eigenvector iteration on the host -- the reference's bytes, masked components included"""
+    for tag, ex in EXPECTED["som"]["lininit"].items():
+        out = tmp_path / (tag + ".cod")
+        run("lininit", "-din", os.path.join(DATA, ex["data"]), "-cout", out, *ex["args"], "-v", 0)
+        assert md5(out) == ex["md5"], tag
+    out = tmp_path / "m.cod"
+    ex = EXPECTED["som"]["lininit"]["ex_hexa"]
+    run("mapinit", "-init", "lin", "-din", os.path.join(DATA, ex["data"]), "-cout", out, *ex["args"], "-v", 0)
+    assert md5(out) == ex["md5"]
 
 
 @pytest.mark.gpu
