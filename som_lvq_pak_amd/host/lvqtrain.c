@@ -35,6 +35,7 @@ int main(int argc, char **argv)
   char *out_code_file = extract_parameter(argc, argv, "-cout", ALWAYS);
   params.length = oatoi(extract_parameter(argc, argv, "-rlen", ALWAYS), 1);
   char *rand_s = extract_parameter(argc, argv, "-rand", OPTION);
+  long buffer = oatoi(extract_parameter(argc, argv, "-buffer", OPTION), 0);
   char *alpha_s = extract_parameter(argc, argv, "-alpha_type", OPTION);
   char *funcname = extract_parameter(argc, argv, "-selfuncs", OPTION);
   char *snapshot_file = extract_parameter(argc, argv, "-snapfile", OPTION);
@@ -75,7 +76,10 @@ int main(int argc, char **argv)
   params.alpha = alpha;
   params.snapshot = snapshot_interval ? &snap : NULL;
   init_random((int)oatoi(rand_s, 0));
-  if (rand_s) randomize_entry_order(data);
+  if (rand_s) {
+    if (buffer > 0 && buffer < data->num_entries) { data->buffer = buffer; data->random_order = 1; }
+    else randomize_entry_order(data);
+  }
   params.alpha_func = alpha_func_by_name(alpha_s, &params.alpha_type);
   if (!params.alpha_func) {
     fprintf(stderr, "Unknown alpha type %s\n", alpha_s);

@@ -50,6 +50,8 @@ struct entries {
   short *fixed_xy;              /* [num_entries][2], -1 = none (NULL if none at all) */
   short *weights;               /* [num_entries] (NULL if none) */
   int labels_needed;
+  long buffer;                  /* > 0 with random_order: -buffer N -rand, rows are presented buffer by buffer, */
+  int random_order;             /*   each buffer reshuffled when it is (re)loaded (datafile.c:237-344)            */
   void *userdata;               /* device mirror handle (as lvq_pak.h:112) */
 };
 

@@ -7,6 +7,7 @@
 #include "pak.h"
 
 #include <float.h>
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -535,6 +536,50 @@ static long segment_end(struct teach_params *t, long start)
   return end < t->length ? end : t->length;
 }
 
+/* The order in which a training run sees the data (datafile.c:237-344, 754-830).  Whole file in
+ * memory: the rows as they are (already shuffled once if -rand), cyclically.  -buffer N together
+ * with -rand: rows [0,N), [N,2N), ... of the FILE, each buffer shuffled with the running orand()
+ * when it is loaded, the file rewound after the last buffer and every run starting at the top.
+ * Each buffer becomes a device data set of its own. */
+struct feed { struct entries *data, *sub; somhip_dataset *ds; long pos, left, first; int per_buffer, with_labels; };
+
+static int feed_open(struct feed *f, struct entries *data, int with_labels)
+{
+  memset(f, 0, sizeof *f);
+  f->data = data; f->with_labels = with_labels;
+  f->per_buffer = data->random_order && data->buffer > 0 && data->buffer < data->num_entries;
+  if (!f->per_buffer) { f->ds = mirror_data(data, with_labels); f->left = -1; return f->ds ? 0 : 1; }
+  return 0;
+}
+/* make sure at least one row is available; returns how many consecutive rows can be taken now
+ * (*first = index of the next one inside the current device data set), 0 on failure */
+static long feed_avail(struct feed *f, long iter, long *first)
+{
+  if (!f->per_buffer) { *first = iter % f->data->num_entries; return LONG_MAX; }
+  if (f->left == 0 || !f->ds) {
+    if (f->ds) { somhip_dataset_destroy(f->ds); f->ds = NULL; }
+    if (f->sub) { close_entries(f->sub); f->sub = NULL; }
+    long n = f->data->num_entries, nb = f->data->buffer < n - f->pos ? f->data->buffer : n - f->pos;
+    long *idx = malloc(sizeof(long) * nb);
+    for (long i = 0; i < nb; i++) idx[i] = f->pos + i;
+    for (long i = 0; i < nb; i++) { long j = orand() % nb, t = idx[i]; idx[i] = idx[j]; idx[j] = t; }   /* datafile.c:1171-1177 */
+    f->sub = pick_rows(f->data, idx, nb);
+    free(idx);
+    f->ds = mirror_data(f->sub, f->with_labels);
+    if (!f->ds) return 0;
+    f->left = nb; f->first = 0;
+    f->pos = f->pos + nb >= n ? 0 : f->pos + nb;
+  }
+  *first = f->first;
+  return f->left;
+}
+static void feed_took(struct feed *f, long count) { if (f->per_buffer) { f->left -= count; f->first += count; } }
+static void feed_close(struct feed *f)
+{
+  if (f->ds) somhip_dataset_destroy(f->ds);
+  if (f->sub) close_entries(f->sub);
+}
+
 struct entries *som_training(struct teach_params *teach)     /* som_rout.c:556-671 */
 {
   struct entries *codes = teach->codes, *data = teach->data;
@@ -545,15 +590,19 @@ struct entries *som_training(struct teach_params *teach)     /* som_rout.c:556-6
     return NULL;
   }
   somhip_codebook *cb = mirror_codes(codes, 0);
-  somhip_dataset *ds = mirror_data(data, 0);
+  struct feed fd;
   struct entries *ret = NULL;
-  if (!cb || !ds) goto done;
+  if (feed_open(&fd, data, 0) || !cb) goto done;
   for (long start = 0; start < teach->length;) {
+    long first, avail = feed_avail(&fd, start, &first);
+    if (avail <= 0) goto done;
     long end = segment_end(teach, start);
+    if (end - start > avail) end = start + avail;
     somhip_som_params sp = { teach->length, teach->alpha, teach->radius, teach->alpha_type,
                              use_fixed_level, use_weights_level, teach->batch > 1 ? teach->batch : 1,
-                             start, end - start, start % data->num_entries };
-    if (somhip_som_train(cb, ds, &sp, NULL, NULL)) { fprintf(stderr, "som_training: %s\n", somhip_last_error()); goto done; }
+                             start, end - start, first };
+    if (somhip_som_train(cb, fd.ds, &sp, NULL, NULL)) { fprintf(stderr, "som_training: %s\n", somhip_last_error()); goto done; }
+    feed_took(&fd, end - start);
     if (teach->snapshot && end - 1 > 0 && (end - 1) % teach->snapshot->interval == 0 && end <= teach->length) {
       if (somhip_codebook_download(cb, codes->points)) goto done;
       ifverbose(2) fprintf(stderr, "Saving snapshot, %ld iterations\n", end - 1);
@@ -565,7 +614,7 @@ struct entries *som_training(struct teach_params *teach)     /* som_rout.c:556-6
   ret = codes;
 done:
   if (cb) somhip_codebook_destroy(cb);
-  if (ds) somhip_dataset_destroy(ds);
+  feed_close(&fd);
   return ret;
 }
 
@@ -575,14 +624,18 @@ static struct entries *lvq_training(struct teach_params *teach, int kind, float 
   struct entries *codes = teach->codes, *data = teach->data;
   if (!data || data->num_entries <= 0) { fprintf(stderr, "%s: can't get data\n", who); return NULL; }
   somhip_codebook *cb = mirror_codes(codes, 1);
-  somhip_dataset *ds = mirror_data(data, 1);
+  struct feed fd;
   struct entries *ret = NULL;
-  if (!cb || !ds) goto done;
+  if (feed_open(&fd, data, 1) || !cb) goto done;
   for (long start = 0; start < teach->length;) {
+    long first, avail = feed_avail(&fd, start, &first);
+    if (avail <= 0) goto done;
     long end = segment_end(teach, start);
+    if (end - start > avail) end = start + avail;
     somhip_lvq_params lp = { kind, teach->length, teach->alpha, teach->alpha_type, winlen, epsilon,
-                             start, end - start, start % data->num_entries };
-    if (somhip_lvq_train(cb, ds, &lp, talpha, NULL, NULL)) { fprintf(stderr, "%s: %s\n", who, somhip_last_error()); goto done; }
+                             start, end - start, first };
+    if (somhip_lvq_train(cb, fd.ds, &lp, talpha, NULL, NULL)) { fprintf(stderr, "%s: %s\n", who, somhip_last_error()); goto done; }
+    feed_took(&fd, end - start);
     if (teach->snapshot && end - 1 > 0 && (end - 1) % teach->snapshot->interval == 0 && end <= teach->length) {
       if (somhip_codebook_download(cb, codes->points)) goto done;
       if (save_snapshot(teach, end - 1)) fprintf(stderr, "snapshot failed\n");
@@ -593,7 +646,7 @@ static struct entries *lvq_training(struct teach_params *teach, int kind, float 
   ret = codes;
 done:
   if (cb) somhip_codebook_destroy(cb);
-  if (ds) somhip_dataset_destroy(ds);
+  feed_close(&fd);
   return ret;
 }
 struct entries *lvq1_training(struct teach_params *t) { return lvq_training(t, SOMHIP_LVQ1, 0, 0, NULL, "lvq1_training"); }
@@ -824,6 +877,17 @@ struct entries *pick_rows(struct entries *src, const long *rows, long n)
     if (e->masks && s->mask) { d->mask = e->masks + k * dim; memcpy(d->mask, s->mask, dim); }
     for (int l = 0; l < s->num_labs; l++) add_entry_label(e, k, s->labels[l]);
     d->weight = s->weight;
+  }
+  if (src->weights) {
+    e->weights = malloc(sizeof(short) * (n + 1));
+    for (long k = 0; k < n; k++) e->weights[k] = src->weights[rows[k]];
+  }
+  if (src->fixed_xy) {
+    e->fixed_xy = malloc(sizeof(short) * 2 * (n + 1));
+    for (long k = 0; k < n; k++) {
+      e->fixed_xy[2 * k] = src->fixed_xy[2 * rows[k]]; e->fixed_xy[2 * k + 1] = src->fixed_xy[2 * rows[k] + 1];
+      e->rows[k].fixed = e->fixed_xy[2 * k] >= 0 ? (struct fixpoint *)(e->fixed_xy + 2 * k) : NULL;
+    }
   }
   return e;
 }

@@ -73,9 +73,8 @@ int main(int argc, char **argv)
 
   init_random((int)oatoi(rand_s, 0));
   if (rand_s) {                                  /* data vectors in random order (vsom.c:171) */
-    if (buffer > 0)
-      fprintf(stderr, "vsom: -buffer with -rand: the whole file is shuffled once (per-buffer reshuffling is not reproduced)\n");
-    randomize_entry_order(data);
+    if (buffer > 0 && buffer < data->num_entries) { data->buffer = buffer; data->random_order = 1; }   /* reshuffled per buffer */
+    else randomize_entry_order(data);                                                               /* once, at load */
   }
   params.alpha_func = alpha_func_by_name(alpha_s, &params.alpha_type);
   if (!params.alpha_func) {

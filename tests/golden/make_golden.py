@@ -73,6 +73,26 @@ def vfind_golden(exp, d):
         exp["som"]["vfind"] = res
 
 
+def buffer_golden(exp, d):
+    """-buffer N with -rand: every buffer is reshuffled when it is (re)loaded (datafile.c:237-344)"""
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, tool, data, cin, args in (
+                ("vsom_b500_r7", "vsom", "ex.dat", "som_init_hexa_bubble.cod",
+                 ["-rlen", 9000, "-alpha", 0.05, "-radius", 10, "-rand", 7, "-buffer", 500]),
+                ("vsom_b3000_r2_gauss", "vsom", "ex.dat", "som_init_hexa_gaussian.cod",
+                 ["-rlen", 4000, "-alpha", 0.04, "-radius", 6, "-rand", 2, "-buffer", 3000]),
+                ("lvq1_b300_r3", "lvq1", "ex1.dat", "lvq_init.cod", ["-rlen", 5000, "-alpha", 0.05, "-rand", 3, "-buffer", 300]),
+                ("olvq1_b777_r9", "olvq1", "ex1.dat", "lvq_init.cod", ["-rlen", 4000, "-rand", 9, "-buffer", 777]),
+                ("lvq3_b5000_r4", "lvq3", "ex1.dat", "lvq_init.cod",      # buffer > file: shuffled once
+                 ["-rlen", 3000, "-alpha", 0.05, "-win", 0.3, "-epsilon", 0.1, "-rand", 4, "-buffer", 5000])):
+            out = os.path.join(tmp, tag + ".cod")
+            run(tool, "-din", d(data), "-cin", cin, "-cout", out, *args)
+            res[tag] = {"tool": tool, "data": data, "cin": cin, "args": [str(a) for a in args], "md5": md5(out)}
+    exp["buffer_rand"] = res
+
+
 def lininit_golden(exp, d):
     """lininit on ex.dat and on a copy of its first 500 rows with every 7th value masked ('x')"""
     import tempfile
@@ -140,6 +160,7 @@ def main():
         lvq_tool_goldens(exp, lambda f: os.path.join(DATA, f))
         vfind_golden(exp, lambda f: os.path.join(DATA, f))
         lininit_golden(exp, lambda f: os.path.join(DATA, f))
+        buffer_golden(exp, lambda f: os.path.join(DATA, f))
         json.dump(exp, open(os.path.join(CLI, "expected.json"), "w"), indent=1, sort_keys=True)
         return
     build()
@@ -212,6 +233,7 @@ def main():
     lvq_tool_goldens(exp, d)
     vfind_golden(exp, d)
     lininit_golden(exp, d)
+    buffer_golden(exp, d)
     json.dump(exp, open(os.path.join(CLI, "expected.json"), "w"), indent=1, sort_keys=True)
 
     # ---------------- in-memory traces through the harness ----------------

@@ -249,6 +249,18 @@ def test_randinit_matches_reference(tools, tmp_path):
 
 
 @pytest.mark.gpu
+def test_buffer_with_rand_matches_reference_cli(tools, tmp_path):
+    """-buffer N -rand: the reference reshuffles every buffer as it is (re)loaded and rewinds the
+    file after the last one (datafile.c:237-344, 754-830); SOM and LVQ loops, N below and above the
+    file length"""
+    for tag, ex in EXPECTED["buffer_rand"].items():
+        out = tmp_path / (tag + ".cod")
+        run(ex["tool"], "-din", os.path.join(DATA, ex["data"]), "-cin", os.path.join(CLI, ex["cin"]), "-cout", out,
+            *ex["args"], "-v", 0)
+        assert md5(out) == ex["md5"], tag
+
+
+@pytest.mark.gpu
 def test_lininit_matches_reference(tools, tmp_path):
     """lininit_codes (som_rout.c:322): mean and centred product sums from the GPU (fp32, rows in
     order), eigenvector iteration on the host -- the reference's bytes, masked components included"""
