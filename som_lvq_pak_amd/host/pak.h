@@ -110,6 +110,7 @@ long add_hit(struct hitlist *, long label);
 long hitlist_label_freq(struct hitlist *, long label);
 
 /* ---- files ---- */
+int pak_parse_float(const char *s, float *out);     /* = sscanf(s, "%f", out) > 0, fast path for plain decimals */
 struct entries *open_entries(const char *name, int labels_needed, int skip_empty);
 int save_entries_wcomments(struct entries *codes, const char *name, const char *comments);
 #define save_entries(c, n) save_entries_wcomments((c), (n), NULL)

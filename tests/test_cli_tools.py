@@ -49,6 +49,20 @@ def test_tools_build_and_usage(tools):
     assert p.returncode == 1 and "Unknown LVQ type nosuch" in p.stderr
 
 
+def test_fast_number_parser_equals_sscanf(tools, tmp_path):
+    """the .dat/.cod reader's fast path for plain decimals must give the float sscanf("%f") gives
+    (reference datafile.c:627, 664) on every token: generated decimals, shortest and 9-digit forms of
+    random floats, values placed on and next to float ties, exponents, junk"""
+    exe = str(tmp_path / "parse_check")
+    host = os.path.join(ROOT, "som_lvq_pak_amd", "host")
+    subprocess.check_call(["gcc", "-O2", "-I", host, "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "helpers", "parse_check.c"), os.path.join(host, "paklib.c"),
+                           "-L", os.path.join(ROOT, "som_lvq_pak_amd"), "-lsomhip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "som_lvq_pak_amd"), "-lm"])
+    p = subprocess.run([exe, "400000"], stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and p.stdout.strip().endswith("mismatches 0"), p.stdout
+
+
 def test_tools_refuse_without_gpu(tools, tmp_path):
     import torch
     if torch.cuda.is_available():
