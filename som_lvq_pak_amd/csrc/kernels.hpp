@@ -1341,31 +1341,67 @@ __global__ __launch_bounds__(256) void k_rerank(CbView cb, const float *__restri
 // keys[sample] with a 64-bit atomic min.  If the list overflows (pathological codebooks: huge
 // numbers of near-ties) K2p does nothing and K2r above re-ranks the whole run group by group.
 // =====================================================================================
-__global__ __launch_bounds__(256) void k_rerank_select(CbView cb, int64_t count, int64_t bpad,
+// order-preserving float <-> uint32 (for atomicMin on values of either sign)
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
+
+// K2m: gmin[b] = min over the shard's row groups of the group minima (ordered-uint encoding; the
+// host presets 0xFFFFFFFF).  Workgroup = 32 consecutive samples (one 128-byte line of wmin) x one
+// chunk of groups, 8 interleaved group phases; one atomicMin per (sample, chunk).
+__global__ __launch_bounds__(256) void k_group_min(int64_t ngroups, int64_t bpad, int64_t chunk,
+                                                   const float *__restrict__ wmin, uint32_t *__restrict__ gmin) {
+  __shared__ float s_min[8][32];
+  const int tid = threadIdx.x, bx = tid & 31, gy = tid >> 5;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 32 + bx;
+  const int64_t g_lo = static_cast<int64_t>(blockIdx.y) * chunk;
+  const int64_t g_hi = g_lo + chunk < ngroups ? g_lo + chunk : ngroups;
+  float m = 3.4e38f;
+  if (b < bpad)
+    for (int64_t g = g_lo + gy; g < g_hi; g += 8) m = fminf(m, wmin[g * bpad + b]);
+  s_min[gy][bx] = m;
+  __syncthreads();
+  if (gy == 0 && b < bpad) {
+#pragma unroll
+    for (int k = 1; k < 8; k++) m = fminf(m, s_min[k][bx]);
+    atomicMin(gmin + b, float_to_ordered(m));
+  }
+}
+
+// K2s: rows of every group within tau of the sample's global minimum -> (sample, row) pairs.
+// Same workgroup shape as K2m (32 samples x a chunk of groups), so the whole wmin matrix is
+// read by thousands of workgroups at once instead of 128 long-running ones.
+__global__ __launch_bounds__(256) void k_rerank_select(CbView cb, int64_t count, int64_t bpad, int64_t chunk,
                                                        const float *__restrict__ wmin,
                                                        const uint64_t *__restrict__ wmask,
                                                        const float *__restrict__ tau,
-                                                       uint32_t cap, uint2 *__restrict__ pairs,
+                                                       const uint32_t *__restrict__ gmin,
+                                                       uint32_t *__restrict__ gcount,
+                                                       uint32_t cap, uint32_t cap_col,
+                                                       uint2 *__restrict__ pairs,
+                                                       uint32_t *__restrict__ col_count,
                                                        uint32_t *__restrict__ pair_count,
                                                        unsigned long long *__restrict__ stats) {
-  // workgroup = 32 consecutive samples (one 128-byte line of wmin) x 8 interleaved group phases
-  __shared__ float s_min[8][32];
+  // The pair list is cut into one segment of cap_col entries per 32-sample column (blockIdx.x), each
+  // with its own counter: a single list counter took ~6 500 same-address atomics per launch and
+  // that serialisation, not the 16 MiB of wmin, was this kernel's time.  A full segment raises
+  // *pair_count above cap, which sends the whole run to the group-granular K2r.
+  __shared__ uint32_t s_cnt[8][32];
   const int tid = threadIdx.x, bx = tid & 31, gy = tid >> 5, lane = tid & 63;
   const int64_t b = static_cast<int64_t>(blockIdx.x) * 32 + bx;
-  float m = 3.4e38f;
-  if (b < bpad)
-    for (int64_t g = gy; g < cb.ngroups; g += 8) m = fminf(m, wmin[g * bpad + b]);
-  s_min[gy][bx] = m;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 8; k++) m = fminf(m, s_min[k][bx]);
+  const int64_t g_lo = static_cast<int64_t>(blockIdx.y) * chunk;
+  const int64_t g_hi = g_lo + chunk < cb.ngroups ? g_lo + chunk : cb.ngroups;
   const bool live = b < count;
-  const float thr = live ? m + tau[b] : -3.4e38f;
+  const float thr = live ? ordered_to_float(gmin[b]) + tau[b] : -3.4e38f;
   unsigned ngr = 0, nrow = 0;
-  for (int64_t g0 = 0; g0 < cb.ngroups; g0 += 8) {
+  for (int64_t g0 = g_lo; g0 < g_hi; g0 += 8) {
     const int64_t g = g0 + gy;
     unsigned long long mask = 0;
-    if (live && g < cb.ngroups && wmin[g * bpad + b] <= thr) {
+    if (live && g < g_hi && wmin[g * bpad + b] <= thr) {
       mask = wmask[g * bpad + b];
       // drop padding rows of the last group: bit 32h+16i+r is row 32i + (r&3) + 8(r>>2) + 4h
       if ((g + 1) * WAVE > cb.n) {
@@ -1388,82 +1424,131 @@ __global__ __launch_bounds__(256) void k_rerank_select(CbView cb, int64_t count,
     }
     const unsigned wave_total = __shfl(pre, WAVE - 1, WAVE);
     unsigned base = 0;
-    if (lane == 0) base = atomicAdd(pair_count, wave_total);
+    if (lane == 0) {
+      base = atomicAdd(col_count + blockIdx.x, wave_total);
+      if (base + wave_total > cap_col) atomicMax(pair_count, cap + 1);
+    }
     base = __shfl(base, 0, WAVE) + pre - n;
     if (n) {
       ngr++; nrow += n;
       unsigned at = base;
       unsigned long long mm = mask;
+      uint2 *seg = pairs + static_cast<size_t>(blockIdx.x) * cap_col;
       while (mm) {
         const int t = __builtin_ctzll(mm);
         mm &= mm - 1;
         const int h = t >> 5, i = (t >> 4) & 1, r = t & 15;
-        if (at < cap)
-          pairs[at] = make_uint2(static_cast<uint32_t>(b),
-                                 static_cast<uint32_t>(g * WAVE + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h));
+        if (at < cap_col)
+          seg[at] = make_uint2(static_cast<uint32_t>(b),
+                               static_cast<uint32_t>(g * WAVE + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h));
         at++;
       }
     }
   }
-  // statistics (per sample: sum the 8 phases through LDS)
-  __syncthreads();
-  s_min[gy][bx] = __uint_as_float(ngr);
+  // statistics: groups re-ranked per sample (summed over the chunks through gcount), totals
+  s_cnt[gy][bx] = ngr;
   __syncthreads();
   if (gy == 0 && live) {
     unsigned tot = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) tot += __float_as_uint(s_min[k][bx]);
-    atomicMax(stats + 2, static_cast<unsigned long long>(tot));
+    for (int k = 0; k < 8; k++) tot += s_cnt[k][bx];
+    if (tot) {
+      const unsigned before = atomicAdd(gcount + b, tot);
+      atomicMax(col_count + gridDim.x * 3 + blockIdx.x, before + tot);      // per-column maximum
+    }
   }
-  unsigned long long a0 = ngr, a1 = nrow;
+  unsigned a0 = ngr, a1 = nrow;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) { a0 += __shfl_xor(a0, off, WAVE); a1 += __shfl_xor(a1, off, WAVE); }
-  if (lane == 0 && a1) { atomicAdd(stats + 0, a0); atomicAdd(stats + 1, a1); }
+  if (lane == 0 && a1) {                                                    // per-column totals; K2p folds them
+    atomicAdd(col_count + gridDim.x * 1 + blockIdx.x, a0);
+    atomicAdd(col_count + gridDim.x * 2 + blockIdx.x, a1);
+  }
+  (void)stats;
 }
+
+constexpr int PAIR_MAX_COLS = 4096;     // 32-sample columns per run (131 072 samples)
 
 __global__ __launch_bounds__(256) void k_rerank_pairs(CbView cb, const float *__restrict__ rows,
                                                       int64_t n_rows, int64_t first, uint32_t cap,
+                                                      uint32_t cap_col, int ncols,
                                                       const uint2 *__restrict__ pairs,
+                                                      const uint32_t *__restrict__ col_count,
                                                       const uint32_t *__restrict__ pair_count,
-                                                      uint64_t *__restrict__ keys) {
-  const uint32_t np = *pair_count;
-  if (np > cap) return;                                  // list overflowed: K2r does the whole run
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= np) return;
-  const uint2 pr = pairs[p];
-  const int64_t row = pr.y;
-  const float4 *crow = reinterpret_cast<const float4 *>(cb.tiles) + ((row >> 6) * cb.d4) * WAVE + (row & 63);
-  const float *x = rows + ((first + pr.x) % n_rows) * cb.d;
+                                                      uint64_t *__restrict__ keys,
+                                                      unsigned long long *__restrict__ stats) {
+  // A fixed, small grid (workgroup launches cost ~50 ns each: a grid sized for the worst case was
+  // the whole cost of this kernel).  Every workgroup builds the same table of 256-entry chunks per
+  // column (prefix sums of the segment fills) and takes chunks round-robin.
+  __shared__ uint32_t s_pref[PAIR_MAX_COLS + 1];
+  __shared__ uint32_t s_scan[256];
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && *pair_count <= cap) {            // the columns' statistics, once
+    for (int c = tid; c < ncols; c += 256) {
+      const uint32_t g = col_count[ncols * 1 + c], r = col_count[ncols * 2 + c];
+      if (r) { atomicAdd(stats + 0, static_cast<unsigned long long>(g)); atomicAdd(stats + 1, static_cast<unsigned long long>(r)); }
+      atomicMax(stats + 2, static_cast<unsigned long long>(col_count[ncols * 3 + c]));
+    }
+  }
+  if (*pair_count > cap) return;                         // a segment overflowed: K2r does the whole run
+  const int per = (ncols + 255) / 256;
+  uint32_t mine = 0;
+  for (int c = tid * per; c < (tid + 1) * per && c < ncols; c++) mine += (col_count[c] + 255u) >> 8;
+  s_scan[tid] = mine;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  {
+    uint32_t run = s_scan[tid] - mine;                   // exclusive prefix of this thread's columns
+    for (int c = tid * per; c < (tid + 1) * per && c < ncols; c++) { s_pref[c] = run; run += (col_count[c] + 255u) >> 8; }
+    if (tid == 255) s_pref[ncols] = s_scan[255];
+  }
+  __syncthreads();
+  const uint32_t total = s_pref[ncols];
   const bool vec = (cb.d & 3) == 0;
-  float acc = 0.0f;
-  // 8 chunks of the row and of the sample in flight per lane (independent loads first)
-  constexpr int UP = 8;
-  int q = 0;
-  for (; q + UP <= cb.d4; q += UP) {
-    float4 cc[UP], xx[UP];
+  for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
+    int lo = 0, hi = ncols;                              // column with s_pref[col] <= id < s_pref[col + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[mid] <= id) lo = mid; else hi = mid; }
+    const uint32_t slot = (id - s_pref[lo]) * 256u + tid;
+    if (slot >= col_count[lo]) continue;
+    const uint2 pr = pairs[static_cast<size_t>(lo) * cap_col + slot];
+    const int64_t row = pr.y;
+    const float4 *crow = reinterpret_cast<const float4 *>(cb.tiles) + ((row >> 6) * cb.d4) * WAVE + (row & 63);
+    const float *x = rows + ((first + pr.x) % n_rows) * cb.d;
+    float acc = 0.0f;
+    // 8 chunks of the row and of the sample in flight per lane (independent loads first)
+    constexpr int UP = 8;
+    int q = 0;
+    for (; q + UP <= cb.d4; q += UP) {
+      float4 cc[UP], xx[UP];
 #pragma unroll
-    for (int u = 0; u < UP; u++) {
-      cc[u] = crow[static_cast<int64_t>(q + u) * WAVE];
-      xx[u] = vec ? reinterpret_cast<const float4 *>(x)[q + u] : load_x4<false>(x, q + u, cb.d);
-    }
+      for (int u = 0; u < UP; u++) {
+        cc[u] = crow[static_cast<int64_t>(q + u) * WAVE];
+        xx[u] = vec ? reinterpret_cast<const float4 *>(x)[q + u] : load_x4<false>(x, q + u, cb.d);
+      }
 #pragma unroll
-    for (int u = 0; u < UP; u++) {
-      acc = sq_acc(acc, cc[u].x, xx[u].x);
-      acc = sq_acc(acc, cc[u].y, xx[u].y);
-      acc = sq_acc(acc, cc[u].z, xx[u].z);
-      acc = sq_acc(acc, cc[u].w, xx[u].w);
+      for (int u = 0; u < UP; u++) {
+        acc = sq_acc(acc, cc[u].x, xx[u].x);
+        acc = sq_acc(acc, cc[u].y, xx[u].y);
+        acc = sq_acc(acc, cc[u].z, xx[u].z);
+        acc = sq_acc(acc, cc[u].w, xx[u].w);
+      }
     }
+    for (; q < cb.d4; q++) {
+      const float4 c = crow[static_cast<int64_t>(q) * WAVE];
+      const float4 xv = vec ? reinterpret_cast<const float4 *>(x)[q] : load_x4<false>(x, q, cb.d);
+      acc = sq_acc(acc, c.x, xv.x);
+      acc = sq_acc(acc, c.y, xv.y);
+      acc = sq_acc(acc, c.z, xv.z);
+      acc = sq_acc(acc, c.w, xv.w);
+    }
+    const uint64_t k = make_key(acc, unit_of_row(cb, row));
+    atomicMin(reinterpret_cast<unsigned long long *>(keys + pr.x), static_cast<unsigned long long>(k));
   }
-  for (; q < cb.d4; q++) {
-    const float4 c = crow[static_cast<int64_t>(q) * WAVE];
-    const float4 xv = vec ? reinterpret_cast<const float4 *>(x)[q] : load_x4<false>(x, q, cb.d);
-    acc = sq_acc(acc, c.x, xv.x);
-    acc = sq_acc(acc, c.y, xv.y);
-    acc = sq_acc(acc, c.z, xv.z);
-    acc = sq_acc(acc, c.w, xv.w);
-  }
-  const uint64_t k = make_key(acc, unit_of_row(cb, row));
-  atomicMin(reinterpret_cast<unsigned long long *>(keys + pr.x), static_cast<unsigned long long>(k));
 }
 
 // =====================================================================================

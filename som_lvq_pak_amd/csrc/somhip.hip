@@ -112,8 +112,8 @@ struct somhip_engine {
   int64_t launches[KID_COUNT] = {0};
   double total_ms[KID_COUNT] = {0};
   // reusable device scratch
-  void *scratch[12] = {nullptr};
-  size_t scratch_bytes[12] = {0};
+  void *scratch[16] = {nullptr};
+  size_t scratch_bytes[16] = {0};
 };
 
 static int engine_scratch(somhip_engine *e, int slot, size_t bytes, void **out) {
@@ -215,7 +215,7 @@ extern "C" void somhip_engine_destroy(somhip_engine *e) {
   (void)hipStreamSynchronize(e->stream);
   for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->pool) (void)hipEventDestroy(ev);
-  for (int i = 0; i < 12; i++) if (e->scratch[i]) (void)hipFree(e->scratch[i]);
+  for (int i = 0; i < 16; i++) if (e->scratch[i]) (void)hipFree(e->scratch[i]);
   if (e->d_stats) (void)hipFree(e->d_stats);
   if (e->online_graph_exec) (void)hipGraphExecDestroy(e->online_graph_exec);
   for (int i = 0; i < 4; i++) {
@@ -551,21 +551,39 @@ static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first
   if (prefilter_only) { *out_wmin = (float *)dwmin; *out_tau = (float *)dtau; return 0; }
   // exact re-rank: row-granular pair path for the usual few candidates, group-granular
   // k_rerank for flagged samples (too many candidates / list full)
-  const uint32_t cap = (uint32_t)std::min<int64_t>(64 * count + 4096, 0x7FFFFFF0);
+  // pair list: one segment per 32-sample column, 64 entries per sample + slack
+  const uint32_t ncols = (uint32_t)(bpad / 32);
+  if (ncols > (uint32_t)PAIR_MAX_COLS) return fail("winner search: more than %d samples in one run", PAIR_MAX_COLS * 32);
+  const uint32_t cap_col = 16384;                    // 512 per sample on average; a full segment -> K2r
+  const uint32_t cap = (uint32_t)std::min<int64_t>((int64_t)ncols * cap_col, 0x7FFFFFF0);
   void *dpairs;
-  CHK(engine_scratch(e, 11, sizeof(uint2) * (size_t)cap + 16, &dpairs));
-  uint32_t *d_paircount = reinterpret_cast<uint32_t *>(e->d_stats + 6);
+  CHK(engine_scratch(e, 11, sizeof(uint2) * (size_t)ncols * cap_col + 16, &dpairs));
+  uint32_t *d_paircount = reinterpret_cast<uint32_t *>(e->d_stats + 6);   // stays 0 unless a segment overflows
+  uint32_t *dcolcount = nullptr;
   HIPCHK(hipMemsetAsync(d_paircount, 0, sizeof(uint32_t), e->stream));
   {
+    // global minimum of the group minima per sample, then the candidate pairs; both over a grid of
+    // (32-sample columns) x (chunks of row groups)
+    void *dg;
+    CHK(engine_scratch(e, 12, sizeof(uint32_t) * (2 * (size_t)bpad + 4 * (size_t)ncols), &dg));
+    uint32_t *dgmin = (uint32_t *)dg, *dgcount = dgmin + bpad;
+    dcolcount = dgcount + bpad;
+    HIPCHK(hipMemsetAsync(dgmin, 0xFF, sizeof(uint32_t) * (size_t)bpad, e->stream));
+    HIPCHK(hipMemsetAsync(dgcount, 0, sizeof(uint32_t) * ((size_t)bpad + 4 * (size_t)ncols), e->stream));   // + {fill, groups, rows, max} per column
+    const int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>(64, (cb->v.ngroups + 63) / 64));
+    const int64_t chunk = ((cb->v.ngroups + nchunks - 1) / nchunks + 7) / 8 * 8;
+    const dim3 sgrid((unsigned)(bpad / 32), (unsigned)((cb->v.ngroups + chunk - 1) / chunk));
     LaunchTimer t(e, KID_RERANK_SELECT);
-    hipLaunchKernelGGL(k_rerank_select, dim3((unsigned)(bpad / 32)), dim3(256), 0, e->stream, cb->v, count, bpad,
-                       (const float *)dwmin, (const uint64_t *)dwmask, (const float *)dtau, cap, (uint2 *)dpairs,
-                       d_paircount, e->d_stats);
+    hipLaunchKernelGGL(k_group_min, sgrid, dim3(256), 0, e->stream, cb->v.ngroups, bpad, chunk, (const float *)dwmin, dgmin);
+    hipLaunchKernelGGL(k_rerank_select, sgrid, dim3(256), 0, e->stream, cb->v, count, bpad, chunk,
+                       (const float *)dwmin, (const uint64_t *)dwmask, (const float *)dtau, (const uint32_t *)dgmin,
+                       dgcount, cap, cap_col, (uint2 *)dpairs, dcolcount, d_paircount, e->d_stats);
   }
   {
     LaunchTimer t(e, KID_RERANK_PAIRS);
-    hipLaunchKernelGGL(k_rerank_pairs, dim3((cap + 255) / 256), dim3(256), 0, e->stream, cb->v, ds->d_rows, ds->n,
-                       first, cap, (const uint2 *)dpairs, (const uint32_t *)d_paircount, d_keys);
+    hipLaunchKernelGGL(k_rerank_pairs, dim3(512), dim3(256), 0, e->stream, cb->v, ds->d_rows,
+                       ds->n, first, cap, cap_col, (int)ncols, (const uint2 *)dpairs, (const uint32_t *)dcolcount,
+                       (const uint32_t *)d_paircount, d_keys, e->d_stats);
   }
   {
     LaunchTimer t(e, KID_RERANK);
@@ -596,7 +614,8 @@ static int scan_keys_top1(somhip_codebook *cb, somhip_dataset *ds, int64_t first
   }
   int64_t nsb = (count + SCAN_S - 1) / SCAN_S;
   e->samples_searched += (uint64_t)count;
-  if (e->scan_mode != SOMHIP_SCAN_DIRECT && count >= MFMA_MIN_SAMPLES && cb->v.n >= 64)
+  if (e->scan_mode != SOMHIP_SCAN_DIRECT && count >= MFMA_MIN_SAMPLES && cb->v.n >= 64 &&
+      count <= (int64_t)PAIR_MAX_COLS * 32)            // longer runs: the direct scan below
     return scan_keys_mfma(cb, ds, first, count, nsb, d_keys);
   void *xt;
   CHK(engine_scratch(e, 1, sizeof(float4) * (size_t)nsb * cb->v.d4 * SCAN_S, &xt));
