@@ -204,8 +204,8 @@ extern "C" int somhip_engine_create(int device, somhip_engine **out) {
   e->device = device;
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   if (const char *ts = getenv("SOMHIP_TAU_SCALE")) { double v = atof(ts); if (v >= 1.0) e->tau_scale = v; }
-  HIPCHK(hipMalloc((void **)&e->d_stats, 8 * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(e->d_stats, 0, 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMalloc((void **)&e->d_stats, (8 + 128) * sizeof(unsigned long long)));   // + 64 {rows, pairs} update counters
+  HIPCHK(hipMemset(e->d_stats, 0, (8 + 128) * sizeof(unsigned long long)));
   *out = e;
   return 0;
 }
@@ -237,9 +237,10 @@ extern "C" int somhip_engine_set_scan_mode(somhip_engine *e, int mode) {
   return 0;
 }
 extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[6]) {
-  unsigned long long h[8];
+  unsigned long long h[8 + 128];
   HIPCHK(hipMemcpyAsync(h, e->d_stats, sizeof h, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < 64; k++) { h[3] += h[8 + 2 * k]; h[4] += h[8 + 2 * k + 1]; }
   out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = e->samples_searched; out[4] = h[3]; out[5] = h[4];
   return 0;
 }
