@@ -428,12 +428,29 @@ __global__ void k_row_norms(CbView cb, float *__restrict__ cn, unsigned int *__r
   if (lane == 0) atomicMax(cn_max_bits, __float_as_uint(m));   // values >= 0: bit order = value order
 }
 
-// tau[b] for the samples of a run (one wave per sample)
+// tau[b] for the samples of a run (one wave per sample).  The same launch presets the per-run
+// scratch of the re-rank (a handful of separate memsets cost more than this whole kernel): the
+// keys (all ones), the per-sample global minima (all ones) and group counts, the per-column
+// counters and the overflow word.
+struct RerankInit {
+  uint64_t *keys;        // [count]
+  uint32_t *gmin;        // [bpad] then gcount [bpad] then col counters [4 * ncols]
+  uint32_t *pair_count;  // overflow word
+  int64_t bpad;
+  int ncols;
+};
 __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int d, int64_t first,
                              int64_t count, const unsigned int *__restrict__ cn_max_bits,
-                             double err_coeff, float *__restrict__ tau) {
+                             double err_coeff, float *__restrict__ tau, RerankInit init) {
   const int64_t b = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  if (init.gmin) {                                       // 64 * count threads >= bpad + 4 * ncols
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t < count && init.keys) init.keys[t] = KEY_NONE;
+    if (t < init.bpad) { init.gmin[t] = 0xFFFFFFFFu; init.gmin[init.bpad + t] = 0u; }
+    if (t < 4 * static_cast<int64_t>(init.ncols)) init.gmin[2 * init.bpad + t] = 0u;
+    if (t == 0) *init.pair_count = 0u;
+  }
   if (b >= count) return;
   const float *x = rows + ((first + b) % n_rows) * d;
   double acc = 0.0;
@@ -660,8 +677,9 @@ __global__ void k_prep_codes_bf16(CbView cb, int d8, float *__restrict__ cn,
 // a run of samples -> bf16 hi/lo sample tiles xt[sb][kb][32][8]
 __global__ void k_pack_samples_bf16(const float *__restrict__ rows, int64_t n_rows, int d, int d8,
                                     int64_t first, int64_t count, uint4 *__restrict__ xhi,
-                                    uint4 *__restrict__ xlo) {
+                                    uint4 *__restrict__ xlo, unsigned int *__restrict__ zero_word) {
   const int64_t sb = blockIdx.x;
+  if (zero_word && sb == 0 && threadIdx.x == 0) *zero_word = 0u;   // max ||c||^2 accumulator of the next kernel
   for (int e = threadIdx.x; e < d8 * 32; e += blockDim.x) {
     const int kb = e / 32, sidx = e % 32;
     const int64_t smp = sb * 32 + sidx;
@@ -1000,15 +1018,21 @@ __global__ __launch_bounds__(256) void k_order_groups(const uint32_t *__restrict
   __shared__ uint32_t s_cnt[8192];                     // host guarantees ngroups <= 8192
   for (int k = threadIdx.x; k < ngroups; k += blockDim.x) s_cnt[k] = cnt[k];
   __syncthreads();
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= ngroups) return;
-  const uint32_t mine = s_cnt[g];
+  // 8 lanes share one group's ranking (an eighth of the comparisons each)
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = t >> 3, part = t & 7;
+  const bool live = g < ngroups;
+  const uint32_t mine = live ? s_cnt[g] : 0u;
   uint32_t rank = 0;
-  for (int k = 0; k < ngroups; k++) {
-    const uint32_t c = s_cnt[k];                       // broadcast read
-    rank += (c > mine) || (c == mine && k < g);
-  }
-  order[rank] = static_cast<uint32_t>(g);
+  if (live)
+    for (int k = part; k < ngroups; k += 8) {
+      const uint32_t c = s_cnt[k];
+      rank += (c > mine) || (c == mine && k < g);
+    }
+  rank += __shfl_xor(rank, 1, WAVE);
+  rank += __shfl_xor(rank, 2, WAVE);
+  rank += __shfl_xor(rank, 4, WAVE);
+  if (live && part == 0) order[rank] = static_cast<uint32_t>(g);
 }
 
 // =====================================================================================

@@ -517,13 +517,20 @@ static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first
     LaunchTimer t(e, KID_PACK_SAMPLES);
     if (bf16)
       hipLaunchKernelGGL(k_pack_samples_bf16, dim3((unsigned)nsb), dim3(256), 0, e->stream, ds->d_rows, ds->n, ds->d,
-                         d8, first, count, xhi, xlo);
+                         d8, first, count, xhi, xlo, cb->d_cnmax);
     else
       hipLaunchKernelGGL(k_pack_samples<SCAN_S>, dim3((unsigned)nsb), dim3(256), 0, e->stream, ds->d_rows, ds->n,
                          ds->d, cb->v.d4, first, count, (float4 *)xt);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemsetAsync(cb->d_cnmax, 0, sizeof(unsigned int), e->stream));
+  if (!bf16) HIPCHK(hipMemsetAsync(cb->d_cnmax, 0, sizeof(unsigned int), e->stream));   // (the bf16 pack kernel zeroes it)
+  // scratch of the re-rank, preset by k_sample_tau
+  const uint32_t ncols = (uint32_t)(bpad / 32);
+  void *dg;
+  CHK(engine_scratch(e, 12, sizeof(uint32_t) * (2 * (size_t)bpad + 4 * (size_t)ncols), &dg));
+  uint32_t *dgmin = (uint32_t *)dg, *dgcount = dgmin + bpad, *dcolcount = dgcount + bpad;
+  uint32_t *d_paircount = reinterpret_cast<uint32_t *>(e->d_stats + 6);   // stays 0 unless a segment overflows
+  RerankInit rinit = {prefilter_only ? nullptr : d_keys, dgmin, d_paircount, bpad, (int)ncols};
   {
     LaunchTimer t(e, KID_NORMS);
     if (bf16)
@@ -534,7 +541,7 @@ static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first
                          cb->v, cb->d_cn, cb->d_cnmax);
     hipLaunchKernelGGL(k_sample_tau, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, e->stream,
                        ds->d_rows, ds->n, ds->d, first, count, (const unsigned int *)cb->d_cnmax,
-                       prefilter_err_coeff(e, ds->d), (float *)dtau);
+                       prefilter_err_coeff(e, ds->d), (float *)dtau, rinit);
   }
   HIPCHK(hipGetLastError());
   {
@@ -552,25 +559,15 @@ static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first
   if (prefilter_only) { *out_wmin = (float *)dwmin; *out_tau = (float *)dtau; return 0; }
   // exact re-rank: row-granular pair path for the usual few candidates, group-granular
   // k_rerank for flagged samples (too many candidates / list full)
-  // pair list: one segment per 32-sample column, 64 entries per sample + slack
-  const uint32_t ncols = (uint32_t)(bpad / 32);
+  // pair list: one segment per 32-sample column
   if (ncols > (uint32_t)PAIR_MAX_COLS) return fail("winner search: more than %d samples in one run", PAIR_MAX_COLS * 32);
   const uint32_t cap_col = 16384;                    // 512 per sample on average; a full segment -> K2r
   const uint32_t cap = (uint32_t)std::min<int64_t>((int64_t)ncols * cap_col, 0x7FFFFFF0);
   void *dpairs;
   CHK(engine_scratch(e, 11, sizeof(uint2) * (size_t)ncols * cap_col + 16, &dpairs));
-  uint32_t *d_paircount = reinterpret_cast<uint32_t *>(e->d_stats + 6);   // stays 0 unless a segment overflows
-  uint32_t *dcolcount = nullptr;
-  HIPCHK(hipMemsetAsync(d_paircount, 0, sizeof(uint32_t), e->stream));
   {
     // global minimum of the group minima per sample, then the candidate pairs; both over a grid of
     // (32-sample columns) x (chunks of row groups)
-    void *dg;
-    CHK(engine_scratch(e, 12, sizeof(uint32_t) * (2 * (size_t)bpad + 4 * (size_t)ncols), &dg));
-    uint32_t *dgmin = (uint32_t *)dg, *dgcount = dgmin + bpad;
-    dcolcount = dgcount + bpad;
-    HIPCHK(hipMemsetAsync(dgmin, 0xFF, sizeof(uint32_t) * (size_t)bpad, e->stream));
-    HIPCHK(hipMemsetAsync(dgcount, 0, sizeof(uint32_t) * ((size_t)bpad + 4 * (size_t)ncols), e->stream));   // + {fill, groups, rows, max} per column
     const int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>(64, (cb->v.ngroups + 63) / 64));
     const int64_t chunk = ((cb->v.ngroups + nchunks - 1) / nchunks + 7) / 8 * 8;
     const dim3 sgrid((unsigned)(bpad / 32), (unsigned)((cb->v.ngroups + chunk - 1) / chunk));
@@ -601,7 +598,9 @@ static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first
 static int scan_keys_top1(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
                           uint64_t *d_keys) {
   somhip_engine *e = cb->e;
-  HIPCHK(hipMemsetAsync(d_keys, 0xFF, sizeof(uint64_t) * (size_t)count, e->stream));
+  const bool use_mfma = !ds->d_mask && e->scan_mode != SOMHIP_SCAN_DIRECT && count >= MFMA_MIN_SAMPLES && cb->v.n >= 64 &&
+                        count <= (int64_t)PAIR_MAX_COLS * 32;      // longer runs: the direct scan below
+  if (!use_mfma) HIPCHK(hipMemsetAsync(d_keys, 0xFF, sizeof(uint64_t) * (size_t)count, e->stream));   // (else k_sample_tau presets them)
   if (ds->d_mask) {
     for (int64_t off = 0; off < count; off += 32768) {      // grid.y limit
       int64_t c = std::min<int64_t>(32768, count - off);
@@ -615,9 +614,7 @@ static int scan_keys_top1(somhip_codebook *cb, somhip_dataset *ds, int64_t first
   }
   int64_t nsb = (count + SCAN_S - 1) / SCAN_S;
   e->samples_searched += (uint64_t)count;
-  if (e->scan_mode != SOMHIP_SCAN_DIRECT && count >= MFMA_MIN_SAMPLES && cb->v.n >= 64 &&
-      count <= (int64_t)PAIR_MAX_COLS * 32)            // longer runs: the direct scan below
-    return scan_keys_mfma(cb, ds, first, count, nsb, d_keys);
+  if (use_mfma) return scan_keys_mfma(cb, ds, first, count, nsb, d_keys);
   void *xt;
   CHK(engine_scratch(e, 1, sizeof(float4) * (size_t)nsb * cb->v.d4 * SCAN_S, &xt));
   {
@@ -1026,7 +1023,7 @@ static int som_update_run(somhip_codebook *cb, somhip_dataset *ds, int64_t data_
     CHK(engine_scratch(e, 0, sizeof(uint32_t) * (size_t)cb->v.ngroups, &p_));
     dorder = (uint32_t *)p_;
     LaunchTimer t(e, KID_DECODE);
-    hipLaunchKernelGGL(k_order_groups, dim3((unsigned)((cb->v.ngroups + 255) / 256)), dim3(256), 0, e->stream,
+    hipLaunchKernelGGL(k_order_groups, dim3((unsigned)((cb->v.ngroups * 8 + 255) / 256)), dim3(256), 0, e->stream,
                        (const uint32_t *)dcnt, (int)cb->v.ngroups, dorder);
     HIPCHK(hipGetLastError());
   }
