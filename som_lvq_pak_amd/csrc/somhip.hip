@@ -547,7 +547,17 @@ static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first
   {
     LaunchTimer t(e, bf16 ? KID_DIST_MFMA_BF16 : KID_DIST_MFMA);
     dim3 grid((unsigned)((nsb + 3) / 4), (unsigned)((cb->v.ngroups + 1) / 2));
-    if (bf16)
+#ifndef SOMHIP_DMA_KB
+#define SOMHIP_DMA_KB 4
+#endif
+#ifndef SOMHIP_DMA_MINB
+#define SOMHIP_DMA_MINB 2
+#endif
+    if (bf16 && (d8 % SOMHIP_DMA_KB) == 0 && !getenv("SOMHIP_NO_LDS_DMA"))
+      hipLaunchKernelGGL((k_dist_mfma_bf16_dma<SOMHIP_DMA_KB, SOMHIP_DMA_MINB>), grid, dim3(256), 0, e->stream, cb->v, d8,
+                         (const uint4 *)cb->d_chi, (const uint4 *)cb->d_clo, (const uint4 *)xhi, (const uint4 *)xlo,
+                         (const float *)cb->d_cn, (const float *)dtau, count, bpad, (float *)dwmin, (uint64_t *)dwmask);
+    else if (bf16)
       hipLaunchKernelGGL(k_dist_mfma_bf16, grid, dim3(256), 0, e->stream, cb->v, d8, (const uint4 *)cb->d_chi,
                          (const uint4 *)cb->d_clo, (const uint4 *)xhi, (const uint4 *)xlo, (const float *)cb->d_cn,
                          (const float *)dtau, count, bpad, (float *)dwmin, (uint64_t *)dwmask);
