@@ -887,6 +887,103 @@ __global__ __launch_bounds__(256, MINB) void k_dist_mfma_bf16_dma(CbView cb, int
   prefilter_epilogue(cb, acc, g0 + wr, st0 + wc * 2, nst, lane, cn, tau, count, bpad, wmin, wmask);
 }
 
+// Wide variant: 128 codes x 256 samples per workgroup, each wave 64 x 128 (2 x 4 MFMA tiles, 24 MFMAs
+// per 16-dim k-step on 4 A + 8 B fragment reads instead of 12 on 8): a quarter less operand traffic
+// into LDS and a quarter fewer LDS reads per MFMA.  Stages of BD_KB = 2 k-blocks (one k-step), two
+// buffers of 24 KiB.
+template <int BD_KB>
+__global__ __launch_bounds__(256, 2) void k_dist_mfma_bf16_wide(CbView cb, int d8,
+                                                                const uint4 *__restrict__ chi,
+                                                                const uint4 *__restrict__ clo,
+                                                                const uint4 *__restrict__ xhi,
+                                                                const uint4 *__restrict__ xlo,
+                                                                const float *__restrict__ cn,
+                                                                const float *__restrict__ tau, int64_t count,
+                                                                int64_t bpad, float *__restrict__ wmin,
+                                                                uint64_t *__restrict__ wmask) {
+  constexpr int CH = 0, CL = 2 * BD_KB * 64, XH = 2 * CL, XL = XH + 8 * BD_KB * 32, TOT = XL + 8 * BD_KB * 32;
+  __shared__ uint4 lds[2 * TOT];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int64_t g0 = static_cast<int64_t>(blockIdx.y) * 2;
+  const int64_t st0 = static_cast<int64_t>(blockIdx.x) * 8;
+  const int64_t nst = bpad / 32;
+  // wave w brings array (w & 1 ? lo : hi) of code group (w >> 1) and of sample tiles 4(w >> 1) .. 4(w >> 1) + 3
+  const int arr = wave & 1, sel = wave >> 1;
+  const int64_t gsrc = g0 + sel < cb.ngroups ? g0 + sel : cb.ngroups - 1;
+  const uint4 *pc = (arr ? clo : chi) + (gsrc * d8) * 64 + lane;
+  const uint4 *px[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int64_t ts = st0 + 4 * sel + t < nst ? st0 + 4 * sel + t : nst - 1;
+    px[t] = (arr ? xlo : xhi) + (ts * d8) * 32 + lane;
+  }
+  const int dc = (arr ? CL : CH) + (sel * BD_KB) * 64;
+  const int dx = (arr ? XL : XH) + ((4 * sel) * BD_KB) * 32;          // + t * BD_KB * 32
+  const int nstage = d8 / BD_KB;
+  auto issue = [&](int s) {
+    uint4 *buf = lds + (s & 1) * TOT;
+    const int kb0 = s * BD_KB;
+#pragma unroll
+    for (int k = 0; k < BD_KB; k++)
+      __builtin_amdgcn_global_load_lds((glb_void *)(pc + (kb0 + k) * 64), (lds_void *)(buf + dc + k * 64), 16, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int k = 0; k < BD_KB / 2; k++)
+        __builtin_amdgcn_global_load_lds((glb_void *)(px[t] + (kb0 + 2 * k) * 32),
+                                         (lds_void *)(buf + dx + t * BD_KB * 32 + k * 64), 16, 0, 0);
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+  issue(0);
+  for (int s = 0; s < nstage; s++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < nstage) issue(s + 1);
+    const uint4 *buf = lds + (s & 1) * TOT;
+#pragma unroll
+    for (int m = 0; m < BD_KB / 2; m++) {
+      const int kb = 2 * m + half;
+      bf16x8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        ah[i] = __builtin_bit_cast(bf16x8, buf[CH + (wr * BD_KB + kb) * 64 + 32 * i + l31]);
+        al[i] = __builtin_bit_cast(bf16x8, buf[CL + (wr * BD_KB + kb) * 64 + 32 * i + l31]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        bh[j] = __builtin_bit_cast(bf16x8, buf[XH + ((wc * 4 + j) * BD_KB + kb) * 32 + l31]);
+        bl[j] = __builtin_bit_cast(bf16x8, buf[XL + ((wc * 4 + j) * BD_KB + kb) * 32 + l31]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int h2 = 0; h2 < 2; h2++) {
+    f32x16 sub[2][2] = {{acc[0][2 * h2], acc[0][2 * h2 + 1]}, {acc[1][2 * h2], acc[1][2 * h2 + 1]}};
+    prefilter_epilogue(cb, sub, g0 + wr, st0 + wc * 4 + 2 * h2, nst, lane, cn, tau, count, bpad, wmin, wmask);
+  }
+}
+
 // =====================================================================================
 // K1m: masked variant, one sample per launch column (rare path: data with 'x'
 // components, lvq_pak.c:65-69).  mask is wave-uniform per component.

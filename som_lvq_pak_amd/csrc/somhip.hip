@@ -553,7 +553,12 @@ static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first
 #ifndef SOMHIP_DMA_MINB
 #define SOMHIP_DMA_MINB 2
 #endif
-    if (bf16 && (d8 % SOMHIP_DMA_KB) == 0 && !getenv("SOMHIP_NO_LDS_DMA"))
+    if (bf16 && (d8 % 2) == 0 && nsb >= 8 && !getenv("SOMHIP_NO_LDS_DMA") && !getenv("SOMHIP_DIST_NARROW")) {
+      dim3 gridw((unsigned)((nsb + 7) / 8), (unsigned)((cb->v.ngroups + 1) / 2));
+      hipLaunchKernelGGL((k_dist_mfma_bf16_wide<2>), gridw, dim3(256), 0, e->stream, cb->v, d8,
+                         (const uint4 *)cb->d_chi, (const uint4 *)cb->d_clo, (const uint4 *)xhi, (const uint4 *)xlo,
+                         (const float *)cb->d_cn, (const float *)dtau, count, bpad, (float *)dwmin, (uint64_t *)dwmask);
+    } else if (bf16 && (d8 % SOMHIP_DMA_KB) == 0 && !getenv("SOMHIP_NO_LDS_DMA"))
       hipLaunchKernelGGL((k_dist_mfma_bf16_dma<SOMHIP_DMA_KB, SOMHIP_DMA_MINB>), grid, dim3(256), 0, e->stream, cb->v, d8,
                          (const uint4 *)cb->d_chi, (const uint4 *)cb->d_clo, (const uint4 *)xhi, (const uint4 *)xlo,
                          (const float *)cb->d_cn, (const float *)dtau, count, bpad, (float *)dwmin, (uint64_t *)dwmask);
