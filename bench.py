@@ -237,6 +237,15 @@ def main():
                 note = ("in-order neighbourhood update on the vector ALU: 3*d flop per (row, iteration) update, "
                         "%.0f row updates per launch counted by the kernel; no FMA allowed (ceiling = half the "
                         "fp32 peak); priced against the fp32 matrix/vector peak" % (rows_upd / max(kl, 1)))
+            elif kname == "k_som_members":
+                pairs = (stats_after["group_updates"] - stats_before["group_updates"]) / max(kl, 1)
+                alg = 16.0 * pairs + 24.0 * B                   # member entries written + winners/scalars read
+                base.update({"bound": "hbm", "achieved": alg / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": alg / avg_s / 1e9 / PEAK_HBM_GBS,
+                             "note": "neighbourhood membership lists: 16 B per (row group, sample) entry written "
+                                     "(%.0f per launch) + 24 B per sample read; integer lattice arithmetic and "
+                                     "ordered compaction, latency-bound" % pairs})
+                return base
             else:
                 alg = 4.0 * n_local * d                         # streaming: one read of the shard per launch
                 base.update({"bound": "hbm", "achieved": alg / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -256,7 +265,11 @@ def main():
             pass
 
         def with_traffic(r):
-            k = pmc.get("kernels", {}).get(r["kernel"])
+            ks = pmc.get("kernels", {})
+            k = ks.get(r["kernel"])
+            if k is None:                                       # template / variant suffixes (k_dist_mfma_bf16_wide)
+                hits = [v for n, v in ks.items() if n.startswith(r["kernel"] + "_")]
+                k = hits[0] if len(hits) == 1 else None
             if k and (xdim, ydim, d, world) == (256, 256, 512, 1):
                 r["traffic"] = {"bytes_per_launch": k["bytes"], "read": k["read_bytes"], "write": k["write_bytes"],
                                 "source": "profiles/r01_pmc_traffic.json: " + pmc.get("source", "")}
