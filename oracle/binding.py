@@ -134,6 +134,8 @@ class Oracle(_Base):
                        _ptr(data, c_float_p), _ptr(dlabels, c_int_p), data.shape[0], length,
                        alpha, alpha_type, winlen, epsilon, _ptr(talpha, c_float_p),
                        _ptr(ti, c_long_p), _ptr(td, c_float_p))
+        if rc == 2:
+            raise FloatingPointError("no winner: the codes diverged (the reference would dereference NULL here)")
         assert rc == 0
         return codes, talpha, ti, td
 

@@ -280,6 +280,9 @@ int orc_lvq_training(int kind, float *codes, const int *clabels, long n, int d,
       if (trace_index) trace_index[le * knn + k] = idx[k];
       if (trace_diff) trace_diff[le * knn + k] = dist[k];
     }
+    /* nothing beat FLT_MAX (codes pushed to infinity by a too large rate): the reference dereferences
+     * a NULL winner here (lvq_rout.c:545); the checker stops and says so */
+    if (idx[0] < 0 || (knn == 2 && idx[1] < 0)) return 2;
     if (kind == ORC_LVQ1) {
       float a = orc_alpha(alpha_type, le, length, alpha);
       float *c = codes + idx[0] * (long)d;

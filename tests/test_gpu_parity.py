@@ -566,3 +566,16 @@ def test_map_wider_than_1024_uses_the_general_lattice_path(eng, E, oracle, batch
     ti, td = E.som_train(cb, ds, 160, 0.2, 300.0, batch=batch)
     assert np.array_equal(ti, oi) and np.array_equal(bits(td), bits(od))
     assert np.array_equal(bits(cb.download()), bits(oc))
+
+
+# --------------------------------------------------------------------------- randomised sweep
+def test_random_parity_sweep_short():
+    """tools/fuzz_parity.py for 20 s: generated map / codebook shapes, ragged dims, batch sizes, masks,
+    weights, fixed points, all LVQ kinds, k-NN scans -- each case bit for bit against the oracle
+    (profiles/r01_fuzz_parity.txt holds a 7-minute run: 15 601 cases)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "20", "4242"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0 and "fuzz ok" in p.stdout, p.stdout[-2000:]
