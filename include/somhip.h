@@ -190,6 +190,13 @@ int  somhip_batch_winner_keys(somhip_codebook *cb, somhip_dataset *ds, int64_t f
 int  somhip_som_batch_update(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
                              int64_t batch_start_iter, int64_t count, int64_t data_first,
                              const uint64_t *dev_keys);
+/* k-NN over a row-sharded codebook (the X2 exchange): dev_keys[count][knn] (knn = 1, 2, 4 or 8) =
+ * this shard's knn best rows per sample, ascending; tag = global row index (SOMHIP_TIE_FIRST) or its
+ * bitwise complement (SOMHIP_TIE_KNN: on equal distances the LATER row sorts first, lvq_pak.c:197).
+ * Missing entries (shard smaller than knn) are all-ones.  All-gather the lists and keep the knn
+ * smallest keys per sample: that is find_winner_knn (lvq_pak.c:152-221) over the whole codebook. */
+int  somhip_batch_topk_keys(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
+                            int knn, int tie, uint64_t *dev_keys);
 /* device scratch helpers for hosts without their own allocator */
 int  somhip_device_alloc(somhip_engine *e, int64_t bytes, void **dev_ptr);
 int  somhip_device_free(somhip_engine *e, void *dev_ptr);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "somhip_lvq_train": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(LvqParams), c_float_p, c_i32_p,
                                    c_float_p]),
     "somhip_batch_winner_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "somhip_batch_topk_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "somhip_som_batch_update": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SomParams), C.c_int64,
                                           C.c_int64, C.c_int64, C.c_void_p]),
     "somhip_device_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),

@@ -706,6 +706,30 @@ extern "C" int somhip_batch_winner_keys(somhip_codebook *cb, somhip_dataset *ds,
   return 0;
 }
 
+// X2: this shard's k best rows per sample as packed keys, ascending; a host all-gathers
+// the shards' lists and keeps the k smallest per sample (keys are unique: tag = global row, or its
+// complement for the k-NN tie order, so the merge IS find_winner_knn over the whole codebook).
+extern "C" int somhip_batch_topk_keys(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
+                                      int knn, int tie, uint64_t *dev_keys) {
+  CHK(check_pair(cb, ds, "somhip_batch_topk_keys"));
+  if (knn < 1 || knn > 8) return fail("somhip_batch_topk_keys: knn %d not in 1..8", knn);
+  if (ds->d_mask) return fail("somhip_batch_topk_keys: masked samples are not supported");
+  if (count <= 0) return 0;
+  HIPCHK(hipSetDevice(cb->e->device));
+  const int t = tie == SOMHIP_TIE_KNN ? 1 : 0;
+  if (knn == 1) {
+    if (t) return fail("somhip_batch_topk_keys: knn 1 is find_winner_euc (SOMHIP_TIE_FIRST)");
+    return somhip_batch_winner_keys(cb, ds, first, count, dev_keys);
+  }
+  if (knn == 2) return scan_keys_topk<2>(cb, ds, first, count, dev_keys, t);
+  if (knn <= 4) {
+    if (knn != 4) return fail("somhip_batch_topk_keys: knn must be 1, 2, 4 or 8");
+    return scan_keys_topk<4>(cb, ds, first, count, dev_keys, t);
+  }
+  if (knn != 8) return fail("somhip_batch_topk_keys: knn must be 1, 2, 4 or 8");
+  return scan_keys_topk<8>(cb, ds, first, count, dev_keys, t);
+}
+
 static void decode_key(uint64_t k, bool inverted, int32_t *index, float *diff) {
   uint32_t bits = (uint32_t)(k >> 32);
   uint32_t tag = (uint32_t)k;

@@ -59,6 +59,39 @@ def allreduce_min_keys(keys, group=None, nonnegative=False):
     return keys
 
 
+def allgather_topk_keys(keys, knn, group=None):
+    """X2: `keys` = this rank's [count, knn] packed keys (uint64 numpy or int64 torch tensor, ascending);
+    returns the knn smallest per sample over all ranks as a uint64 numpy array [count, knn].  Keys are
+    unique per row (tag = global row, complemented for the k-NN tie order), so sorting the union IS
+    find_winner_knn over the whole codebook (reference lvq_pak.c:152-221)."""
+    import torch
+    import torch.distributed as dist
+    t = keys if isinstance(keys, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(keys).view(np.int64))
+    t = t.reshape(-1, knn)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        host_staged = t.is_cuda and dist.get_backend(group) == "gloo"
+        src = t.cpu() if host_staged else t
+        parts = [torch.empty_like(src) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, src, group=group)
+        allk = torch.cat(parts, dim=1)
+    else:
+        allk = t
+    u = allk.cpu().numpy().view(np.uint64)
+    u = np.sort(u, axis=1)[:, :knn]                  # unsigned order = (distance, tag) order
+    return np.ascontiguousarray(u)
+
+
+def unpack_knn_keys(keys):
+    """(diff, index) of keys written with SOMHIP_TIE_KNN (tag = ~row); all-ones -> (-1, -1)."""
+    keys = np.asarray(keys).view(np.uint64)
+    none = keys == np.uint64(0xFFFFFFFFFFFFFFFF)
+    diff = (keys >> np.uint64(32)).astype(np.uint32).view(np.float32).copy()
+    index = ((~keys) & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    diff[none] = -1.0
+    index[none] = -1
+    return diff, index
+
+
 class ShardedSom:
     """Mini-batch SOM training over a row-sharded codebook.
 

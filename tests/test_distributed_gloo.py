@@ -90,6 +90,20 @@ def _worker(rank, world, port, q):
                 want, wi, _ = orc.som_train(ini, xdim, ydim, topol, neigh, x, length, 0.09, 3.0, batch=B)
                 out[case] = (bool(np.array_equal(full.view(np.uint32), want.view(np.uint32))),
                              bool(np.array_equal(widx, wi)))
+        # X2: every rank contributes the k best keys of its shard; the sorted union is the global k-NN
+        x, _ = synth(60, 90, 7)
+        codes = np.concatenate([x[:50], x[:15]]).astype(np.float32)        # duplicates: knn tie order matters
+        n = codes.shape[0]
+        r0, r1 = sharded.shard_rows(n, world, rank)
+        wi, wd, _ = orc.winners(codes[r0:r1], x, 2, True)
+        tag = (~(wi + r0).astype(np.uint64)) & np.uint64(0xFFFFFFFF)
+        keys = (wd.view(np.uint32).astype(np.uint64) << np.uint64(32)) | tag
+        keys[wi < 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        merged = sharded.allgather_topk_keys(keys, 2)
+        gd, gi = sharded.unpack_knn_keys(merged)
+        fi, fd, _ = orc.winners(codes, x, 2, True)
+        if rank == 0:
+            out["knn"] = (bool(np.array_equal(gi, fi)), bool(np.array_equal(gd.view(np.uint32), fd.view(np.uint32))))
         # the all-ones "no winner" key must lose a signed MIN
         k = torch.tensor([-1 if rank == 0 else 5, 7 + rank], dtype=torch.int64)
         sharded.allreduce_min_keys(k)
@@ -115,6 +129,7 @@ def test_sharded_training_world2_gloo():
     assert out[0] == (True, True)
     assert out[1] == (True, True)
     assert out["none_key"] == [5, 7]
+    assert out["knn"] == (True, True)
 
 
 def test_shard_rows_and_keys():

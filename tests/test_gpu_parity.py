@@ -261,6 +261,34 @@ def test_som_row_sharded_two_phase(eng, E, oracle):
         eng.device_free(k)
 
 
+@pytest.mark.parametrize("knn", [2, 4, 8])
+def test_knn_row_sharded_merge(eng, E, oracle, knn):
+    """X2 on one GPU: three uneven row shards, each shard's k best keys per sample, union sorted --
+    must equal find_winner_knn over the whole codebook (duplicated rows included: on equal distances
+    the later row comes first, lvq_pak.c:197)."""
+    from som_lvq_pak_amd import sharded
+    x, _ = synth(77, 300, 24)
+    rs = np.random.RandomState(knn)
+    codes = np.concatenate([x[rs.randint(0, 300, 400)], x[:40], x[:40]]).astype(np.float32)   # exact ties
+    n = codes.shape[0]
+    want_i, want_d, _ = oracle.winners(codes, x, knn, True)
+    cuts = [0, 130, 131, n]
+    ds = E.Dataset(eng, x)
+    parts = []
+    for a, b in zip(cuts, cuts[1:]):
+        cb = E.Codebook(eng, codes[a:b], row_offset=a, n_global=n)
+        kb = eng.device_alloc(8 * 300 * knn)
+        assert eng.lib.somhip_batch_topk_keys(cb.h, ds.h, 0, 300, knn, E.TIE_KNN, kb) == 0
+        hk = np.empty((300, knn), dtype=np.uint64)
+        assert eng.lib.somhip_copy_to_host(eng.h, hk.ctypes.data_as(C.c_void_p), kb, 8 * 300 * knn) == 0
+        eng.device_free(kb)
+        parts.append(hk)
+    merged = np.sort(np.concatenate(parts, axis=1), axis=1)[:, :knn]
+    gd, gi = sharded.unpack_knn_keys(merged)
+    assert np.array_equal(gi, want_i)
+    assert np.array_equal(bits(gd), bits(want_d))
+
+
 # --------------------------------------------------------------------------- lvq*_training
 LVQ_CASES = [("lvq1", 1, {}), ("olvq1", 2, {}), ("lvq2", 3, {"winlen": 0.3}),
              ("lvq3", 4, {"winlen": 0.3, "epsilon": 0.1}), ("lvq1_invt", 1, {"alpha_type": 2})]
