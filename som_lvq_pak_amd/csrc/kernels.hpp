@@ -674,6 +674,43 @@ __global__ void k_prep_codes_bf16(CbView cb, int d8, float *__restrict__ cn,
   if (lane == 0) atomicMax(cn_max_bits, __float_as_uint(m));
 }
 
+// the same for a short list of rows (the rows one batch of the LVQ engine corrected): one wave per
+// row, lanes over the k-blocks; the norm is a wave sum (any summation order satisfies the bound tau
+// is built from)
+__global__ __launch_bounds__(256) void k_prep_rows_bf16(CbView cb, int d8, const int32_t *__restrict__ list,
+                                                        int nlist, float *__restrict__ cn,
+                                                        uint4 *__restrict__ chi, uint4 *__restrict__ clo) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= nlist) return;
+  const int64_t row = list[w];
+  const int64_t g = row >> 6;
+  const int rl = static_cast<int>(row & 63);
+  float acc = 0.0f;
+  for (int kb = lane; kb < d8; kb += WAVE) {
+    const float4 a = *tile_ptr(cb, g, 2 * kb, rl);
+    const float4 b = (2 * kb + 1 < cb.d4) ? *tile_ptr(cb, g, 2 * kb + 1, rl) : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc += a.x * a.x; acc += a.y * a.y; acc += a.z * a.z; acc += a.w * a.w;
+    acc += b.x * b.x; acc += b.y * b.y; acc += b.z * b.z; acc += b.w * b.w;
+    uint4 hi, lo;
+    split8(a, b, hi, lo);
+    chi[(g * d8 + kb) * WAVE + rl] = hi;
+    clo[(g * d8 + kb) * WAVE + rl] = lo;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, WAVE);
+  if (lane == 0) cn[row] = acc;
+}
+// max over the live rows of cn (bits; the host zeroes *cn_max_bits first)
+__global__ __launch_bounds__(256) void k_max_norm(CbView cb, const float *__restrict__ cn,
+                                                  unsigned int *__restrict__ cn_max_bits) {
+  float m = 0.0f;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; r < cb.n;
+       r += static_cast<int64_t>(gridDim.x) * blockDim.x) m = fmaxf(m, cn[r]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, WAVE));
+  if ((threadIdx.x & 63) == 0) atomicMax(cn_max_bits, __float_as_uint(m));
+}
+
 // a run of samples -> bf16 hi/lo sample tiles xt[sb][kb][32][8]
 __global__ void k_pack_samples_bf16(const float *__restrict__ rows, int64_t n_rows, int d, int d8,
                                     int64_t first, int64_t count, uint4 *__restrict__ xhi,
@@ -1548,6 +1585,212 @@ __global__ __launch_bounds__(256) void k_rerank(CbView cb, const float *__restri
 }
 
 // =====================================================================================
+// K2k: exact k nearest rows per sample behind the same pre-filter (the frozen candidate lists of
+// the batched LVQ engine, K6).  With m_K = the K-th smallest group minimum of s~ and delta = tau/2
+// the bound on |s~ + ||x||^2 - d|:  the K rows that realise the K smallest group minima have exact
+// distances <= m_K + ||x||^2 + delta, so the exact K-th distance is at most that, and every row of
+// the exact top K has s~ <= m_K + 2 delta -- its group's minimum is <= m_K + tau.  One wave per
+// sample: each lane keeps the K smallest minima of its strided groups, K extraction rounds give
+// m_K; then ALL 64 rows of every group with minimum <= m_K + tau get the reference's arithmetic
+// (lane = row, dims in order) and are merged into the running K best keys (tag = row, or ~row for
+// the k-NN tie order).
+// =====================================================================================
+template <int K>
+__global__ __launch_bounds__(256) void k_rerank_topk(CbView cb, const float *__restrict__ rows,
+                                                     int64_t n_rows, int64_t first, int64_t count,
+                                                     int64_t bpad, const float *__restrict__ wmin,
+                                                     const float *__restrict__ tau, int tie_knn,
+                                                     uint64_t *__restrict__ keys_out) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= count) return;
+  // ---- m_K: K-th smallest group minimum
+  float mine[K];
+#pragma unroll
+  for (int t = 0; t < K; t++) mine[t] = 3.4e38f;
+  for (int64_t g = lane; g < cb.ngroups; g += WAVE) {
+    float v = wmin[g * bpad + b];
+#pragma unroll
+    for (int t = 0; t < K; t++) {                        // sorted insertion
+      const float lo = fminf(mine[t], v);
+      v = fmaxf(mine[t], v);
+      mine[t] = lo;
+    }
+  }
+  float mk = 3.4e38f;
+  for (int t = 0; t < K; t++) {                          // K rounds: smallest head, its lane pops
+    float h = mine[0];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) h = fminf(h, __shfl_xor(h, off, WAVE));
+    mk = h;
+    const unsigned long long who = __ballot(mine[0] == h);
+    if (lane == __builtin_ctzll(who)) {
+#pragma unroll
+      for (int u = 0; u + 1 < K; u++) mine[u] = mine[u + 1];
+      mine[K - 1] = 3.4e38f;
+    }
+  }
+  const float thr = (mk >= 3.0e38f) ? 3.4e38f : mk + tau[b];      // fewer than K groups: take them all
+  // ---- exact distances of every row of the surviving groups, running K best
+  const float *x = rows + ((first + b) % n_rows) * cb.d;
+  const bool vec = (cb.d & 3) == 0;
+  uint64_t top[K];
+#pragma unroll
+  for (int t = 0; t < K; t++) top[t] = KEY_NONE;
+  for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
+    const int64_t gl = gb + lane;
+    const bool q = gl < cb.ngroups && wmin[gl * bpad + b] <= thr;
+    uint64_t ball = __ballot(q);
+    while (ball) {
+      const int t = __builtin_ctzll(ball);
+      ball &= ball - 1;
+      const int64_t g = gb + t;
+      const int64_t row = g * WAVE + lane;
+      const float acc = vec ? online_stream<false, true, false, true, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr)
+                            : online_stream<false, true, false, false, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr);
+      const uint32_t grow = unit_of_row(cb, row);
+      uint64_t k = row < cb.n ? make_key(acc, tie_knn ? ~grow : grow) : KEY_NONE;
+      for (int it = 0; it < K; it++) {                   // at most K rows of one group can enter
+        const uint64_t best = wave_min_u64_dpp(k);
+        if (best >= top[K - 1]) break;                   // wave-uniform
+        uint64_t v = best;
+#pragma unroll
+        for (int u = 0; u < K; u++) {                    // sorted insertion (keys are unique)
+          const uint64_t lo = top[u] < v ? top[u] : v;
+          v = top[u] < v ? v : top[u];
+          top[u] = lo;
+        }
+        if (k == best) k = KEY_NONE;
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < K; t++) keys_out[b * K + t] = top[t];
+  }
+}
+
+// K2k in three launches for big codebooks, where one wave per sample (above) would stream megabytes
+// alone: (1) k_topk_select -- per sample m_K, then the (sample, group) pairs of the surviving groups
+// as one contiguous block of a shared list; (2) k_topk_pairs -- one wave per pair: exact distances of
+// the group's 64 rows, its K smallest keys; (3) k_topk_merge -- per sample the K smallest of its
+// pairs' keys.  A full list (*overflow != 0) sends the run to the one-wave kernel instead.
+struct TopkSpan { uint32_t start, n; };
+
+template <int K>
+__global__ __launch_bounds__(256) void k_topk_select(CbView cb, int64_t count, int64_t bpad,
+                                                     const float *__restrict__ wmin,
+                                                     const float *__restrict__ tau, uint32_t cap,
+                                                     uint2 *__restrict__ pairs, TopkSpan *__restrict__ span,
+                                                     uint32_t *__restrict__ counter /* [0] fill, [1] overflow */) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= count) return;
+  float mine[K];
+#pragma unroll
+  for (int t = 0; t < K; t++) mine[t] = 3.4e38f;
+  for (int64_t g = lane; g < cb.ngroups; g += WAVE) {
+    float v = wmin[g * bpad + b];
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      const float lo = fminf(mine[t], v);
+      v = fmaxf(mine[t], v);
+      mine[t] = lo;
+    }
+  }
+  float mk = 3.4e38f;
+  for (int t = 0; t < K; t++) {
+    float h = mine[0];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) h = fminf(h, __shfl_xor(h, off, WAVE));
+    mk = h;
+    const unsigned long long who = __ballot(mine[0] == h);
+    if (lane == __builtin_ctzll(who)) {
+#pragma unroll
+      for (int u = 0; u + 1 < K; u++) mine[u] = mine[u + 1];
+      mine[K - 1] = 3.4e38f;
+    }
+  }
+  const float thr = (mk >= 3.0e38f) ? 3.4e38f : mk + tau[b];
+  uint32_t total = 0;
+  for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
+    const int64_t gl = gb + lane;
+    total += __popcll(__ballot(gl < cb.ngroups && wmin[gl * bpad + b] <= thr));
+  }
+  uint32_t start = 0;
+  if (lane == 0) {
+    start = atomicAdd(counter, total);
+    if (start + total > cap) atomicMax(counter + 1, 1u);
+    span[b].start = start; span[b].n = total;
+  }
+  start = __shfl(start, 0, WAVE);
+  if (start + total > cap) return;
+  uint32_t at = start;
+  for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
+    const int64_t gl = gb + lane;
+    const bool q = gl < cb.ngroups && wmin[gl * bpad + b] <= thr;
+    const unsigned long long ball = __ballot(q);
+    if (q) pairs[at + __popcll(ball & ((1ull << lane) - 1))] = make_uint2(static_cast<uint32_t>(b), static_cast<uint32_t>(gl));
+    at += __popcll(ball);
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_topk_pairs(CbView cb, const float *__restrict__ rows, int64_t n_rows,
+                                                    int64_t first, int tie_knn, const uint2 *__restrict__ pairs,
+                                                    const uint32_t *__restrict__ counter,
+                                                    uint64_t *__restrict__ partial /* [pair][K] */) {
+  if (counter[1]) return;
+  const uint32_t np = counter[0];
+  const int lane = threadIdx.x & 63;
+  const bool vec = (cb.d & 3) == 0;
+  const uint32_t nw = gridDim.x * 4;
+  for (uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < np; p += nw) {
+    const uint2 pr = pairs[p];
+    const float *x = rows + ((first + pr.x) % n_rows) * cb.d;
+    const int64_t g = pr.y, row = g * WAVE + lane;
+    const float acc = vec ? online_stream<false, true, false, true, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr)
+                          : online_stream<false, true, false, false, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr);
+    const uint32_t grow = unit_of_row(cb, row);
+    uint64_t k = row < cb.n ? make_key(acc, tie_knn ? ~grow : grow) : KEY_NONE;
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      const uint64_t best = wave_min_u64_dpp(k);
+      if (lane == 0) partial[static_cast<size_t>(p) * K + t] = best;
+      if (k == best) k = KEY_NONE;
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_topk_merge(int64_t count, const TopkSpan *__restrict__ span,
+                                                    const uint64_t *__restrict__ partial,
+                                                    const uint32_t *__restrict__ counter,
+                                                    uint64_t *__restrict__ keys_out) {
+  if (counter[1]) return;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= count) return;
+  const TopkSpan sp = span[b];
+  const uint64_t *p = partial + static_cast<size_t>(sp.start) * K;
+  const int total = static_cast<int>(sp.n) * K;
+  uint64_t prev = 0;
+  bool firstround = true;
+  for (int t = 0; t < K; t++) {
+    uint64_t mine = KEY_NONE;
+    for (int j = lane; j < total; j += WAVE) {
+      const uint64_t v = p[j];
+      if ((firstround || v > prev) && v < mine) mine = v;   // keys are unique
+    }
+    const uint64_t best = wave_min_u64_dpp(mine);
+    if (lane == 0) keys_out[b * K + t] = best;
+    prev = best;
+    firstround = false;
+    if (best == KEY_NONE) { for (int u = t + 1; u < K; u++) if (lane == 0) keys_out[b * K + u] = KEY_NONE; break; }
+  }
+}
+
+// =====================================================================================
 // K2s / K2p: the usual case of the re-rank, row-granular.  K2s (one wave per sample) finds
 // the groups within tau of the global minimum and appends the masked rows as
 // (sample, row) pairs to one list; K2p (one lane per pair) recomputes each pair's distance
@@ -1947,6 +2190,7 @@ __global__ __launch_bounds__(LVQ_BT) void k_lvq_batch_apply(CbView cb, const flo
                                                             const uint64_t *__restrict__ cand,
                                                             const LvqStep *__restrict__ st, int knn,
                                                             int slots, uint64_t *__restrict__ fin,
+                                                            int32_t *__restrict__ mod_rows,
                                                             LvqBatchCtl *__restrict__ ctl) {
   extern __shared__ float4 lvq_dyn[];
   const int d4 = cb.d4;
@@ -2237,6 +2481,8 @@ __global__ __launch_bounds__(LVQ_BT) void k_lvq_batch_apply(CbView cb, const flo
   }
   if (talpha)
     for (int sl = tid; sl < m; sl += LVQ_BT) talpha[s_slot_row[sl]] = s_slot_ta[sl];
+  if (mod_rows)
+    for (int sl = tid; sl < m; sl += LVQ_BT) mod_rows[sl] = s_slot_row[sl];
   if (tid == 0) {
     ctl->consumed = j; ctl->nmod = m; ctl->reason = reason; ctl->pad = 0;
     for (int k = 0; k < 4; k++) ctl->cycles[k] = cyc[k];

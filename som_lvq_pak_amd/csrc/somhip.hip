@@ -112,8 +112,8 @@ struct somhip_engine {
   int64_t launches[KID_COUNT] = {0};
   double total_ms[KID_COUNT] = {0};
   // reusable device scratch
-  void *scratch[16] = {nullptr};
-  size_t scratch_bytes[16] = {0};
+  void *scratch[20] = {nullptr};
+  size_t scratch_bytes[20] = {0};
 };
 
 static int engine_scratch(somhip_engine *e, int slot, size_t bytes, void **out) {
@@ -215,7 +215,7 @@ extern "C" void somhip_engine_destroy(somhip_engine *e) {
   (void)hipStreamSynchronize(e->stream);
   for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->pool) (void)hipEventDestroy(ev);
-  for (int i = 0; i < 16; i++) if (e->scratch[i]) (void)hipFree(e->scratch[i]);
+  for (int i = 0; i < 20; i++) if (e->scratch[i]) (void)hipFree(e->scratch[i]);
   if (e->d_stats) (void)hipFree(e->d_stats);
   if (e->online_graph_exec) (void)hipGraphExecDestroy(e->online_graph_exec);
   for (int i = 0; i < 4; i++) {
@@ -298,6 +298,7 @@ struct somhip_codebook {
   float *d_cn = nullptr;           // [ngroups*64] squared row norms (MFMA pre-filter)
   unsigned int *d_cnmax = nullptr; // bits of max squared norm
   uint4 *d_chi = nullptr, *d_clo = nullptr;   // bf16 hi/lo tiles [ngroups][d8][64] (bf16 pre-filter)
+  bool prep_current = false;       // one-shot: the caller has just brought d_cn/d_chi/d_clo up to date itself
 };
 struct somhip_dataset {
   somhip_engine *e = nullptr;
@@ -314,6 +315,7 @@ struct somhip_dataset {
 
 static int upload_rows(somhip_codebook *cb, const float *rows) {
   somhip_engine *e = cb->e;
+  cb->prep_current = false;
   void *stage;
   size_t bytes = sizeof(float) * (size_t)cb->v.n * cb->v.d;
   CHK(engine_scratch(e, 0, bytes, &stage));
@@ -523,6 +525,8 @@ static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first
                          ds->d, cb->v.d4, first, count, (float4 *)xt);
   }
   HIPCHK(hipGetLastError());
+  const bool prep_was_current = cb->prep_current;
+  cb->prep_current = false;                              // one-shot
   if (!bf16) HIPCHK(hipMemsetAsync(cb->d_cnmax, 0, sizeof(unsigned int), e->stream));   // (the bf16 pack kernel zeroes it)
   // scratch of the re-rank, preset by k_sample_tau
   const uint32_t ncols = (uint32_t)(bpad / 32);
@@ -533,7 +537,10 @@ static int scan_keys_mfma(somhip_codebook *cb, somhip_dataset *ds, int64_t first
   RerankInit rinit = {prefilter_only ? nullptr : d_keys, dgmin, d_paircount, bpad, (int)ncols};
   {
     LaunchTimer t(e, KID_NORMS);
-    if (bf16)
+    if (bf16 && prep_was_current) {
+      // the LVQ engine re-split exactly the rows its last batch corrected: only the maximum is due
+      hipLaunchKernelGGL(k_max_norm, dim3(64), dim3(256), 0, e->stream, cb->v, (const float *)cb->d_cn, cb->d_cnmax);
+    } else if (bf16)
       hipLaunchKernelGGL(k_prep_codes_bf16, dim3((unsigned)((cb->v.ngroups + 3) / 4)), dim3(256), 0, e->stream,
                          cb->v, d8, cb->d_cn, cb->d_cnmax, cb->d_chi, cb->d_clo);
     else
@@ -652,6 +659,41 @@ template <int K>
 static int scan_keys_topk(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
                           uint64_t *d_keys /*[count][K]*/, int tie_knn = 1) {
   somhip_engine *e = cb->e;
+  // big codebooks: bf16 pre-filter + exact re-rank of the surviving row groups (kernels.hpp K2k)
+  const bool force_mfma = getenv("SOMHIP_TOPK_MFMA") != nullptr, no_mfma = getenv("SOMHIP_TOPK_DIRECT") != nullptr;
+  if (!no_mfma && e->scan_mode == SOMHIP_SCAN_MFMA_BF16 && !ds->d_mask && count >= MFMA_MIN_SAMPLES &&
+      cb->v.n >= (force_mfma ? 64 : 4096) && count <= (int64_t)PAIR_MAX_COLS * 32) {
+    const int64_t nsb = (count + SCAN_S - 1) / SCAN_S;
+    float *dw = nullptr, *dt = nullptr;
+    CHK(scan_keys_mfma(cb, ds, first, count, nsb, nullptr, true, &dw, &dt));
+    const int64_t bpad = nsb * SCAN_S;
+    // pair-parallel re-rank (three launches); the one-wave-per-sample kernel only if the list overflows
+    const uint32_t cap = (uint32_t)std::min<int64_t>(count * 128 + 4096, 0x3FFFFFF0);
+    void *dpairs, *dspan, *dpart, *dcnt;
+    CHK(engine_scratch(e, 11, sizeof(uint2) * (size_t)cap, &dpairs));
+    CHK(engine_scratch(e, 2, sizeof(uint64_t) * (size_t)cap * K, &dpart));
+    CHK(engine_scratch(e, 15, sizeof(TopkSpan) * (size_t)count + 16, &dspan));
+    uint32_t *dcounter = reinterpret_cast<uint32_t *>(e->d_stats + 7);
+    (void)dcnt;
+    HIPCHK(hipMemsetAsync(dcounter, 0, 2 * sizeof(uint32_t), e->stream));
+    LaunchTimer t(e, KID_RERANK);
+    hipLaunchKernelGGL(k_topk_select<K>, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, e->stream, cb->v, count, bpad,
+                       (const float *)dw, (const float *)dt, cap, (uint2 *)dpairs, (TopkSpan *)dspan, dcounter);
+    hipLaunchKernelGGL(k_topk_pairs<K>, dim3(1024), dim3(256), 0, e->stream, cb->v, ds->d_rows, ds->n, first, tie_knn,
+                       (const uint2 *)dpairs, (const uint32_t *)dcounter, (uint64_t *)dpart);
+    hipLaunchKernelGGL(k_topk_merge<K>, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, e->stream, count,
+                       (const TopkSpan *)dspan, (const uint64_t *)dpart, (const uint32_t *)dcounter, d_keys);
+    HIPCHK(hipGetLastError());
+    uint32_t hc[2];
+    HIPCHK(hipMemcpyAsync(hc, dcounter, sizeof hc, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (hc[1]) {                                         // list full: every sample through the one-wave kernel
+      hipLaunchKernelGGL(k_rerank_topk<K>, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, e->stream, cb->v, ds->d_rows,
+                         ds->n, first, count, bpad, (const float *)dw, (const float *)dt, tie_knn, d_keys);
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
+  }
   int64_t nsb = (count + SCAN_S - 1) / SCAN_S;
   int nblk = (int)((cb->v.ngroups + 3) / 4);
   void *xt, *part;
@@ -942,6 +984,7 @@ static void launch_online_any(somhip_engine *e, const somhip_codebook *cb, const
 static int som_train_online(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
                             int32_t *trace_index, float *trace_diff) {
   somhip_engine *e = cb->e;
+  cb->prep_current = false;
   const int64_t CH = ONLINE_CHUNK;
   const bool G = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN, M = ds->d_mask != nullptr;
   void *dslot, *dsc, *drow;
@@ -1030,6 +1073,7 @@ static int som_train_online(somhip_codebook *cb, somhip_dataset *ds, const somhi
 static int som_update_run(somhip_codebook *cb, somhip_dataset *ds, int64_t data_first, int64_t count,
                           const uint64_t *d_keys, const StepScalars *d_sc) {
   somhip_engine *e = cb->e;
+  cb->prep_current = false;
   const bool G = cb->v.neigh == SOMHIP_NEIGH_GAUSSIAN, M = ds->d_mask != nullptr;
 #ifndef SOMHIP_UPD_QW
 #define SOMHIP_UPD_QW 8
@@ -1182,8 +1226,11 @@ static int lvq_train_batched(somhip_codebook *cb, somhip_dataset *ds, const somh
   void *dcand, *dfin, *dst, *dctl;
   CHK(engine_scratch(e, 3, sizeof(uint64_t) * (size_t)BMAX * LVQ_K0, &dcand));
   CHK(engine_scratch(e, 4, sizeof(LvqStep) * (size_t)BMAX, &dst));
-  CHK(engine_scratch(e, 5, sizeof(uint64_t) * (size_t)BMAX * 2, &dfin));
-  CHK(engine_scratch(e, 6, sizeof(LvqBatchCtl), &dctl));
+  CHK(engine_scratch(e, 13, sizeof(uint64_t) * (size_t)BMAX * 2, &dfin));    // (5..7, 11, 12 belong to the pre-filter)
+  CHK(engine_scratch(e, 14, sizeof(LvqBatchCtl), &dctl));
+  void *dmod;
+  CHK(engine_scratch(e, 16, sizeof(int32_t) * LVQ_BT, &dmod));
+  cb->prep_current = false;
   std::vector<LvqStep> hst((size_t)BMAX);
   std::vector<uint64_t> hfin((size_t)BMAX * 2);
   const float ratio = (1 - p->winlen) / (1 + p->winlen);                  // lvq_rout.c:770, fp32
@@ -1211,7 +1258,7 @@ static int lvq_train_batched(somhip_codebook *cb, somhip_dataset *ds, const somh
       hipLaunchKernelGGL(k_lvq_batch_apply, dim3(1), dim3(LVQ_BT), dyn, e->stream, cb->v, ds->d_rows, ds->n, row0,
                          (int)c, (const int32_t *)cb->d_labels, p->kind == SOMHIP_OLVQ1 ? cb->d_talpha : nullptr,
                          (const uint64_t *)dcand, (const LvqStep *)dst, knn, slots, (uint64_t *)dfin,
-                         (LvqBatchCtl *)dctl);
+                         (int32_t *)dmod, (LvqBatchCtl *)dctl);
     }
     HIPCHK(hipGetLastError());
     LvqBatchCtl ctl;
@@ -1235,6 +1282,15 @@ static int lvq_train_batched(somhip_codebook *cb, somhip_dataset *ds, const somh
     }
     off += ctl.consumed;
     n_batches++;
+    // the bf16 copies / norms of exactly the rows this batch corrected, so that the next batch's
+    // pre-filter (big codebooks, scan_keys_topk) needs no pass over the whole codebook
+    if (cb->d_chi && cb->d_cn && e->scan_mode == SOMHIP_SCAN_MFMA_BF16 && !getenv("SOMHIP_ALWAYS_PREP")) {
+      if (ctl.nmod > 0)
+        hipLaunchKernelGGL(k_prep_rows_bf16, dim3((unsigned)((ctl.nmod + 3) / 4)), dim3(256), 0, e->stream, cb->v,
+                           (cb->v.d4 + 1) / 2, (const int32_t *)dmod, (int)ctl.nmod, cb->d_cn, cb->d_chi, cb->d_clo);
+      HIPCHK(hipGetLastError());
+      cb->prep_current = true;
+    }
     if (ctl.reason == 1) e->lvq_stop_list++;
     if (ctl.reason == 2) e->lvq_stop_cache++;
     for (int k = 0; k < 4; k++) e->lvq_cycles[k] += (uint64_t)ctl.cycles[k];
@@ -1250,6 +1306,7 @@ static int lvq_train_batched(somhip_codebook *cb, somhip_dataset *ds, const somh
 extern "C" int somhip_lvq_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_lvq_params *p,
                                 float *talpha, int32_t *trace_index, float *trace_diff) {
   CHK(check_pair(cb, ds, "somhip_lvq_train"));
+  cb->prep_current = false;
   if (!p) return fail("somhip_lvq_train: null params");
   if (p->kind < SOMHIP_LVQ1 || p->kind > SOMHIP_LVQ3) return fail("Unknown LVQ type %d", p->kind);
   if (!cb->d_labels) return fail("somhip_lvq_train: codebook has no labels");

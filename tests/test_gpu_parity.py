@@ -289,6 +289,26 @@ def test_knn_row_sharded_merge(eng, E, oracle, knn):
     assert np.array_equal(bits(gd), bits(want_d))
 
 
+@pytest.mark.parametrize("knn,rule", [(2, "knn"), (4, "knn"), (8, "knn")])
+@pytest.mark.parametrize("n,d,m", [(300, 24, 100), (5000, 64, 257), (4096, 130, 64), (70, 512, 33)])
+def test_topk_behind_the_mfma_prefilter(eng, E, oracle, knn, rule, n, d, m):
+    """k nearest rows through the bf16 pre-filter + group re-rank (K2k) = find_winner_knn: random codes,
+    duplicated rows (exact ties: later row first), tight clusters that put many rows within tau"""
+    x, _ = synth(n + d, m, d, k=4, spread=2.0)
+    rs = np.random.RandomState(n)
+    codes = (x[rs.randint(0, m, n)] + 0.01 * rs.standard_normal((n, d))).astype(np.float32)
+    codes[n // 2:n // 2 + 20] = codes[:20]                     # exact duplicates
+    want_i, want_d, _ = oracle.winners(codes, x, knn, True)
+    cb, ds = E.Codebook(eng, codes), E.Dataset(eng, x)
+    os.environ["SOMHIP_TOPK_MFMA"] = "1"
+    try:
+        gi, gd, _ = E.find_winners(cb, ds, knn=knn, tie=E.TIE_KNN)
+    finally:
+        os.environ.pop("SOMHIP_TOPK_MFMA", None)
+    assert np.array_equal(gi, want_i)
+    assert np.array_equal(bits(gd), bits(want_d))
+
+
 # --------------------------------------------------------------------------- lvq*_training
 LVQ_CASES = [("lvq1", 1, {}), ("olvq1", 2, {}), ("lvq2", 3, {"winlen": 0.3}),
              ("lvq3", 4, {"winlen": 0.3, "epsilon": 0.1}), ("lvq1_invt", 1, {"alpha_type": 2})]
@@ -338,9 +358,11 @@ def _lvq_both_engines(eng, E, oracle, kind, codes, clab, x, lab, length, alpha, 
     """exact batched engine (default) and one-launch-per-iteration engine against the oracle"""
     oc, ol, oi, od = oracle.lvq_train(kind, codes, clab, x, lab, length, alpha, **kw)
     stats = {}
-    for mode in ("batched", "online"):
+    for mode in ("batched", "batched_mfma_topk", "online"):
         if mode == "online":
             os.environ["SOMHIP_LVQ_ONLINE"] = "1"
+        if mode == "batched_mfma_topk":
+            os.environ["SOMHIP_TOPK_MFMA"] = "1"
         try:
             cb = E.Codebook(eng, codes, labels=clab)
             ds = E.Dataset(eng, x, labels=lab)
@@ -349,6 +371,7 @@ def _lvq_both_engines(eng, E, oracle, kind, codes, clab, x, lab, length, alpha, 
             after = eng.lvq_stats()
         finally:
             os.environ.pop("SOMHIP_LVQ_ONLINE", None)
+            os.environ.pop("SOMHIP_TOPK_MFMA", None)
         assert np.array_equal(ti, oi), mode
         assert np.array_equal(bits(td), bits(od)), mode
         assert np.array_equal(bits(cb.download()), bits(oc)), mode
