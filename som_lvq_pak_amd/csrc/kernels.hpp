@@ -2296,8 +2296,10 @@ __global__ __launch_bounds__(LVQ_BT) void k_lvq_batch_apply(CbView cb, const flo
       }
 #define LVQ_PROD(P, RC, RX)                                                               \
       _Pragma("unroll") for (int u = 0; u < 4; u++) {                                     \
-        P[4 * u + 0] = lvq_sq(RC[u].x, RX[u].x); P[4 * u + 1] = lvq_sq(RC[u].y, RX[u].y);  \
-        P[4 * u + 2] = lvq_sq(RC[u].z, RX[u].z); P[4 * u + 3] = lvq_sq(RC[u].w, RX[u].w);  \
+        const f32x2 t0_ = f32x2{RC[u].x, RC[u].y} - f32x2{RX[u].x, RX[u].y};              \
+        const f32x2 t1_ = f32x2{RC[u].z, RC[u].w} - f32x2{RX[u].z, RX[u].w};              \
+        const f32x2 p0_ = t0_ * t0_, p1_ = t1_ * t1_;   /* v_pk_*: each half rounded like the scalar op */ \
+        P[4 * u + 0] = p0_.x; P[4 * u + 1] = p0_.y; P[4 * u + 2] = p1_.x; P[4 * u + 3] = p1_.y; \
       }
 #define LVQ_SUM(P) _Pragma("unroll") for (int i = 0; i < 16; i++) acc = acc + P[i];
       if (nblk > 0) {
