@@ -1105,6 +1105,7 @@ struct MemberEntry { uint32_t sample; float alpha; unsigned long long mask; };  
 template <bool GAUSS>
 __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
                                                      const int2 *__restrict__ bxy,
+                                                     const uint64_t *__restrict__ keys,
                                                      const StepScalars *__restrict__ sc,
                                                      uint32_t *__restrict__ cnt,
                                                      MemberEntry *__restrict__ ent,
@@ -1139,8 +1140,19 @@ __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
       unsigned long long m = 0;
       float alpha_b = 0.f;
       if (b < count) {
-      const int2 w = bxy[b];
       const StepScalars s = sc[b];
+      int2 w;
+      if (keys) {                                        // winners decoded here (K4a's rule), no extra launch
+        w = make_int2(-1, -1);
+        if (s.reach >= 0) {
+          uint32_t widx = 0xFFFFFFFFu;
+          if (s.fixed >= 0) widx = static_cast<uint32_t>(s.fixed);
+          else { const uint64_t k = keys[b]; if (static_cast<uint32_t>(k >> 32) < FLT_MAX_BITS) widx = static_cast<uint32_t>(k); }
+          if (widx != 0xFFFFFFFFu) w = make_int2(static_cast<int>(widx % xdim), static_cast<int>(widx / xdim));
+        }
+      } else {
+        w = bxy[b];
+      }
       alpha_b = s.alpha;
       // reach (rows) >= radius/0.866 + 1 also bounds the x extent (unit spacing 1, half-unit shifts)
       if (w.x >= 0 && w.y + s.reach >= g_ty0 && w.y - s.reach <= g_ty1 &&

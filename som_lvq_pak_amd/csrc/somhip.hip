@@ -1086,18 +1086,18 @@ static int som_update_run(somhip_codebook *cb, somhip_dataset *ds, int64_t data_
   CHK(engine_scratch(e, 8, sizeof(int2) * (size_t)count, &dbxy));
   CHK(engine_scratch(e, 9, sizeof(uint32_t) * (size_t)cb->v.ngroups, &dcnt));
   CHK(engine_scratch(e, 10, sizeof(MemberEntry) * (size_t)cb->v.ngroups * (size_t)count, &dent));
-  {
+  if (G) {                                                // the gaussian update needs the decoded winners itself
     LaunchTimer t(e, KID_DECODE);
     hipLaunchKernelGGL(k_decode_winners, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream,
                        d_keys, d_sc, count, cb->v.xdim, (int2 *)dbxy);
+    HIPCHK(hipGetLastError());
   }
-  HIPCHK(hipGetLastError());
   {
     LaunchTimer t(e, KID_MEMBERS);
     if (G) hipLaunchKernelGGL(k_som_members<true>, dim3((unsigned)cb->v.ngroups), dim3(256), 0, e->stream, cb->v, count,
-                              (const int2 *)dbxy, d_sc, (uint32_t *)dcnt, (MemberEntry *)dent, e->d_stats);
+                              (const int2 *)dbxy, (const uint64_t *)nullptr, d_sc, (uint32_t *)dcnt, (MemberEntry *)dent, e->d_stats);
     else hipLaunchKernelGGL(k_som_members<false>, dim3((unsigned)cb->v.ngroups), dim3(256), 0, e->stream, cb->v, count,
-                            (const int2 *)dbxy, d_sc, (uint32_t *)dcnt, (MemberEntry *)dent, e->d_stats);
+                            (const int2 *)nullptr, d_keys, d_sc, (uint32_t *)dcnt, (MemberEntry *)dent, e->d_stats);
   }
   HIPCHK(hipGetLastError());
   uint32_t *dorder = nullptr;
