@@ -15,11 +15,12 @@ LIB       = som_lvq_pak_amd/libsomhip.so
 all: lib oracle tools
 
 lib: $(LIB)
-$(LIB): $(CSRC)/somhip.hip $(CSRC)/kernels.hpp $(CSRC)/schedule.hpp include/somhip.h Makefile
+KHDR      = $(CSRC)/kernels.hpp $(wildcard $(CSRC)/kernels/*.hpp)
+$(LIB): $(CSRC)/somhip.hip $(KHDR) $(CSRC)/schedule.hpp include/somhip.h Makefile
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/somhip.hip
 
 # device ISA of the kernels, for the no-FMA check (tests/test_build.py) and for reading
-isa: $(CSRC)/somhip.hip $(CSRC)/kernels.hpp
+isa: $(CSRC)/somhip.hip $(KHDR)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) --cuda-device-only -S -o build/somhip_gfx950.s $(CSRC)/somhip.hip \
 	    -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt || true

@@ -1,0 +1,493 @@
+// kernels/rerank.hpp -- K2r/K2k/K2m/K2s/K2p: exact re-rank behind the pre-filter (top-1 and top-k)
+// (part of kernels.hpp; see the notes at the top of that file)
+#pragma once
+#include "som_online.hpp"
+
+namespace somhip {
+
+// =====================================================================================
+// K2r: exact re-rank.  One wave per sample: global minimum of the group minima, then
+// for every group within tau of it, the masked rows' distances with the reference's
+// arithmetic (lane = row, dims in order, sub/mul/add), exact (distance, index) minimum.
+// stats[0] += groups re-ranked, stats[1] += rows re-ranked, stats[2] = max groups/sample.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_rerank(CbView cb, const float *__restrict__ rows,
+                                                int64_t n_rows, int64_t first, int64_t count,
+                                                int64_t bpad, const float *__restrict__ wmin,
+                                                const uint64_t *__restrict__ wmask,
+                                                const float *__restrict__ tau,
+                                                const uint32_t *__restrict__ pair_count, uint32_t cap,
+                                                uint64_t *__restrict__ keys,
+                                                unsigned long long *__restrict__ stats) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= count) return;
+  if (pair_count && *pair_count <= cap) return;          // the pair path handled the run
+  float m = 3.4e38f;
+  for (int64_t g = lane; g < cb.ngroups; g += WAVE) m = fminf(m, wmin[g * bpad + b]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off, WAVE));
+  const float thr = m + tau[b];
+  const float *x = rows + ((first + b) % n_rows) * cb.d;
+  const bool vec = (cb.d & 3) == 0;
+  uint64_t best = KEY_NONE;
+  unsigned ngroups_done = 0, nrows_done = 0;
+  for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
+    const int64_t gl = gb + lane;
+    const bool q = gl < cb.ngroups && wmin[gl * bpad + b] <= thr;
+    uint64_t ball = __ballot(q);
+    while (ball) {
+      const int t = __builtin_ctzll(ball);
+      ball &= ball - 1;
+      const int64_t g = gb + t;
+      const uint64_t mask = wmask[g * bpad + b];
+      // lane -> code row of the group: the mask bit of row rr is
+      //   half = (rr>>2)&1, i = rr>>5, r = (rr&3) + 4*((rr&31)>>3)  -> bit 32*half + 16*i + r
+      const int rr = lane;
+      const int hbit = (rr >> 2) & 1, ib = rr >> 5, rb = (rr & 3) + 4 * ((rr & 31) >> 3);
+      const bool mine = (mask >> (32 * hbit + 16 * ib + rb)) & 1ull;
+      const int64_t row = g * WAVE + lane;
+      // same arithmetic and order as k_scan_exact / k_som_online_step, loads pipelined
+      const float acc = vec ? online_stream<false, true, false, true, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr)
+                            : online_stream<false, true, false, false, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr);
+      const bool ok = mine && row < cb.n;
+      const uint64_t k = ok ? make_key(acc, unit_of_row(cb, row)) : KEY_NONE;
+      best = k < best ? k : best;
+      ngroups_done++;
+      nrows_done += __popcll(mask);
+    }
+  }
+  best = wave_min_u64(best);
+  if (lane == 0) {
+    atomicMin(reinterpret_cast<unsigned long long *>(keys + b), static_cast<unsigned long long>(best));
+    atomicAdd(stats + 0, static_cast<unsigned long long>(ngroups_done));
+    atomicAdd(stats + 1, static_cast<unsigned long long>(nrows_done));
+    atomicMax(stats + 2, static_cast<unsigned long long>(ngroups_done));
+  }
+}
+
+// =====================================================================================
+// K2k: exact k nearest rows per sample behind the same pre-filter (the frozen candidate lists of
+// the batched LVQ engine, K6).  With m_K = the K-th smallest group minimum of s~ and delta = tau/2
+// the bound on |s~ + ||x||^2 - d|:  the K rows that realise the K smallest group minima have exact
+// distances <= m_K + ||x||^2 + delta, so the exact K-th distance is at most that, and every row of
+// the exact top K has s~ <= m_K + 2 delta -- its group's minimum is <= m_K + tau.  One wave per
+// sample: each lane keeps the K smallest minima of its strided groups, K extraction rounds give
+// m_K; then ALL 64 rows of every group with minimum <= m_K + tau get the reference's arithmetic
+// (lane = row, dims in order) and are merged into the running K best keys (tag = row, or ~row for
+// the k-NN tie order).
+// =====================================================================================
+template <int K>
+__global__ __launch_bounds__(256) void k_rerank_topk(CbView cb, const float *__restrict__ rows,
+                                                     int64_t n_rows, int64_t first, int64_t count,
+                                                     int64_t bpad, const float *__restrict__ wmin,
+                                                     const float *__restrict__ tau, int tie_knn,
+                                                     uint64_t *__restrict__ keys_out) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= count) return;
+  // ---- m_K: K-th smallest group minimum
+  float mine[K];
+#pragma unroll
+  for (int t = 0; t < K; t++) mine[t] = 3.4e38f;
+  for (int64_t g = lane; g < cb.ngroups; g += WAVE) {
+    float v = wmin[g * bpad + b];
+#pragma unroll
+    for (int t = 0; t < K; t++) {                        // sorted insertion
+      const float lo = fminf(mine[t], v);
+      v = fmaxf(mine[t], v);
+      mine[t] = lo;
+    }
+  }
+  float mk = 3.4e38f;
+  for (int t = 0; t < K; t++) {                          // K rounds: smallest head, its lane pops
+    float h = mine[0];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) h = fminf(h, __shfl_xor(h, off, WAVE));
+    mk = h;
+    const unsigned long long who = __ballot(mine[0] == h);
+    if (lane == __builtin_ctzll(who)) {
+#pragma unroll
+      for (int u = 0; u + 1 < K; u++) mine[u] = mine[u + 1];
+      mine[K - 1] = 3.4e38f;
+    }
+  }
+  const float thr = (mk >= 3.0e38f) ? 3.4e38f : mk + tau[b];      // fewer than K groups: take them all
+  // ---- exact distances of every row of the surviving groups, running K best
+  const float *x = rows + ((first + b) % n_rows) * cb.d;
+  const bool vec = (cb.d & 3) == 0;
+  uint64_t top[K];
+#pragma unroll
+  for (int t = 0; t < K; t++) top[t] = KEY_NONE;
+  for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
+    const int64_t gl = gb + lane;
+    const bool q = gl < cb.ngroups && wmin[gl * bpad + b] <= thr;
+    uint64_t ball = __ballot(q);
+    while (ball) {
+      const int t = __builtin_ctzll(ball);
+      ball &= ball - 1;
+      const int64_t g = gb + t;
+      const int64_t row = g * WAVE + lane;
+      const float acc = vec ? online_stream<false, true, false, true, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr)
+                            : online_stream<false, true, false, false, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr);
+      const uint32_t grow = unit_of_row(cb, row);
+      uint64_t k = row < cb.n ? make_key(acc, tie_knn ? ~grow : grow) : KEY_NONE;
+      for (int it = 0; it < K; it++) {                   // at most K rows of one group can enter
+        const uint64_t best = wave_min_u64_dpp(k);
+        if (best >= top[K - 1]) break;                   // wave-uniform
+        uint64_t v = best;
+#pragma unroll
+        for (int u = 0; u < K; u++) {                    // sorted insertion (keys are unique)
+          const uint64_t lo = top[u] < v ? top[u] : v;
+          v = top[u] < v ? v : top[u];
+          top[u] = lo;
+        }
+        if (k == best) k = KEY_NONE;
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < K; t++) keys_out[b * K + t] = top[t];
+  }
+}
+
+// K2k in three launches for big codebooks, where one wave per sample (above) would stream megabytes
+// alone: (1) k_topk_select -- per sample m_K, then the (sample, group) pairs of the surviving groups
+// as one contiguous block of a shared list; (2) k_topk_pairs -- one wave per pair: exact distances of
+// the group's 64 rows, its K smallest keys; (3) k_topk_merge -- per sample the K smallest of its
+// pairs' keys.  A full list (*overflow != 0) sends the run to the one-wave kernel instead.
+struct TopkSpan { uint32_t start, n; };
+
+template <int K>
+__global__ __launch_bounds__(256) void k_topk_select(CbView cb, int64_t count, int64_t bpad,
+                                                     const float *__restrict__ wmin,
+                                                     const float *__restrict__ tau, uint32_t cap,
+                                                     uint2 *__restrict__ pairs, TopkSpan *__restrict__ span,
+                                                     uint32_t *__restrict__ counter /* [0] fill, [1] overflow */) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= count) return;
+  float mine[K];
+#pragma unroll
+  for (int t = 0; t < K; t++) mine[t] = 3.4e38f;
+  for (int64_t g = lane; g < cb.ngroups; g += WAVE) {
+    float v = wmin[g * bpad + b];
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      const float lo = fminf(mine[t], v);
+      v = fmaxf(mine[t], v);
+      mine[t] = lo;
+    }
+  }
+  float mk = 3.4e38f;
+  for (int t = 0; t < K; t++) {
+    float h = mine[0];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) h = fminf(h, __shfl_xor(h, off, WAVE));
+    mk = h;
+    const unsigned long long who = __ballot(mine[0] == h);
+    if (lane == __builtin_ctzll(who)) {
+#pragma unroll
+      for (int u = 0; u + 1 < K; u++) mine[u] = mine[u + 1];
+      mine[K - 1] = 3.4e38f;
+    }
+  }
+  const float thr = (mk >= 3.0e38f) ? 3.4e38f : mk + tau[b];
+  uint32_t total = 0;
+  for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
+    const int64_t gl = gb + lane;
+    total += __popcll(__ballot(gl < cb.ngroups && wmin[gl * bpad + b] <= thr));
+  }
+  uint32_t start = 0;
+  if (lane == 0) {
+    start = atomicAdd(counter, total);
+    if (start + total > cap) atomicMax(counter + 1, 1u);
+    span[b].start = start; span[b].n = total;
+  }
+  start = __shfl(start, 0, WAVE);
+  if (start + total > cap) return;
+  uint32_t at = start;
+  for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
+    const int64_t gl = gb + lane;
+    const bool q = gl < cb.ngroups && wmin[gl * bpad + b] <= thr;
+    const unsigned long long ball = __ballot(q);
+    if (q) pairs[at + __popcll(ball & ((1ull << lane) - 1))] = make_uint2(static_cast<uint32_t>(b), static_cast<uint32_t>(gl));
+    at += __popcll(ball);
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_topk_pairs(CbView cb, const float *__restrict__ rows, int64_t n_rows,
+                                                    int64_t first, int tie_knn, const uint2 *__restrict__ pairs,
+                                                    const uint32_t *__restrict__ counter,
+                                                    uint64_t *__restrict__ partial /* [pair][K] */) {
+  if (counter[1]) return;
+  const uint32_t np = counter[0];
+  const int lane = threadIdx.x & 63;
+  const bool vec = (cb.d & 3) == 0;
+  const uint32_t nw = gridDim.x * 4;
+  for (uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < np; p += nw) {
+    const uint2 pr = pairs[p];
+    const float *x = rows + ((first + pr.x) % n_rows) * cb.d;
+    const int64_t g = pr.y, row = g * WAVE + lane;
+    const float acc = vec ? online_stream<false, true, false, true, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr)
+                          : online_stream<false, true, false, false, 8>(cb, g, lane, false, 0.f, x, x, nullptr, nullptr);
+    const uint32_t grow = unit_of_row(cb, row);
+    uint64_t k = row < cb.n ? make_key(acc, tie_knn ? ~grow : grow) : KEY_NONE;
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+      const uint64_t best = wave_min_u64_dpp(k);
+      if (lane == 0) partial[static_cast<size_t>(p) * K + t] = best;
+      if (k == best) k = KEY_NONE;
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_topk_merge(int64_t count, const TopkSpan *__restrict__ span,
+                                                    const uint64_t *__restrict__ partial,
+                                                    const uint32_t *__restrict__ counter,
+                                                    uint64_t *__restrict__ keys_out) {
+  if (counter[1]) return;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= count) return;
+  const TopkSpan sp = span[b];
+  const uint64_t *p = partial + static_cast<size_t>(sp.start) * K;
+  const int total = static_cast<int>(sp.n) * K;
+  uint64_t prev = 0;
+  bool firstround = true;
+  for (int t = 0; t < K; t++) {
+    uint64_t mine = KEY_NONE;
+    for (int j = lane; j < total; j += WAVE) {
+      const uint64_t v = p[j];
+      if ((firstround || v > prev) && v < mine) mine = v;   // keys are unique
+    }
+    const uint64_t best = wave_min_u64_dpp(mine);
+    if (lane == 0) keys_out[b * K + t] = best;
+    prev = best;
+    firstround = false;
+    if (best == KEY_NONE) { for (int u = t + 1; u < K; u++) if (lane == 0) keys_out[b * K + u] = KEY_NONE; break; }
+  }
+}
+
+// =====================================================================================
+// K2s / K2p: the usual case of the re-rank, row-granular.  K2s (one wave per sample) finds
+// the groups within tau of the global minimum and appends the masked rows as
+// (sample, row) pairs to one list; K2p (one lane per pair) recomputes each pair's distance
+// with the reference's arithmetic (dims in order, sub/mul/add) and folds the key into
+// keys[sample] with a 64-bit atomic min.  If the list overflows (pathological codebooks: huge
+// numbers of near-ties) K2p does nothing and K2r above re-ranks the whole run group by group.
+// =====================================================================================
+// order-preserving float <-> uint32 (for atomicMin on values of either sign)
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
+
+// K2m: gmin[b] = min over the shard's row groups of the group minima (ordered-uint encoding; the
+// host presets 0xFFFFFFFF).  Workgroup = 32 consecutive samples (one 128-byte line of wmin) x one
+// chunk of groups, 8 interleaved group phases; one atomicMin per (sample, chunk).
+__global__ __launch_bounds__(256) void k_group_min(int64_t ngroups, int64_t bpad, int64_t chunk,
+                                                   const float *__restrict__ wmin, uint32_t *__restrict__ gmin) {
+  __shared__ float s_min[8][32];
+  const int tid = threadIdx.x, bx = tid & 31, gy = tid >> 5;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 32 + bx;
+  const int64_t g_lo = static_cast<int64_t>(blockIdx.y) * chunk;
+  const int64_t g_hi = g_lo + chunk < ngroups ? g_lo + chunk : ngroups;
+  float m = 3.4e38f;
+  if (b < bpad)
+    for (int64_t g = g_lo + gy; g < g_hi; g += 8) m = fminf(m, wmin[g * bpad + b]);
+  s_min[gy][bx] = m;
+  __syncthreads();
+  if (gy == 0 && b < bpad) {
+#pragma unroll
+    for (int k = 1; k < 8; k++) m = fminf(m, s_min[k][bx]);
+    atomicMin(gmin + b, float_to_ordered(m));
+  }
+}
+
+// K2s: rows of every group within tau of the sample's global minimum -> (sample, row) pairs.
+// Same workgroup shape as K2m (32 samples x a chunk of groups), so the whole wmin matrix is
+// read by thousands of workgroups at once instead of 128 long-running ones.
+__global__ __launch_bounds__(256) void k_rerank_select(CbView cb, int64_t count, int64_t bpad, int64_t chunk,
+                                                       const float *__restrict__ wmin,
+                                                       const uint64_t *__restrict__ wmask,
+                                                       const float *__restrict__ tau,
+                                                       const uint32_t *__restrict__ gmin,
+                                                       uint32_t *__restrict__ gcount,
+                                                       uint32_t cap, uint32_t cap_col,
+                                                       uint2 *__restrict__ pairs,
+                                                       uint32_t *__restrict__ col_count,
+                                                       uint32_t *__restrict__ pair_count,
+                                                       unsigned long long *__restrict__ stats) {
+  // The pair list is cut into one segment of cap_col entries per 32-sample column (blockIdx.x), each
+  // with its own counter: a single list counter took ~6 500 same-address atomics per launch and
+  // that serialisation, not the 16 MiB of wmin, was this kernel's time.  A full segment raises
+  // *pair_count above cap, which sends the whole run to the group-granular K2r.
+  __shared__ uint32_t s_cnt[8][32];
+  const int tid = threadIdx.x, bx = tid & 31, gy = tid >> 5, lane = tid & 63;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 32 + bx;
+  const int64_t g_lo = static_cast<int64_t>(blockIdx.y) * chunk;
+  const int64_t g_hi = g_lo + chunk < cb.ngroups ? g_lo + chunk : cb.ngroups;
+  const bool live = b < count;
+  const float thr = live ? ordered_to_float(gmin[b]) + tau[b] : -3.4e38f;
+  unsigned ngr = 0, nrow = 0;
+  for (int64_t g0 = g_lo; g0 < g_hi; g0 += 8) {
+    const int64_t g = g0 + gy;
+    unsigned long long mask = 0;
+    if (live && g < g_hi && wmin[g * bpad + b] <= thr) {
+      mask = wmask[g * bpad + b];
+      // drop padding rows of the last group: bit 32h+16i+r is row 32i + (r&3) + 8(r>>2) + 4h
+      if ((g + 1) * WAVE > cb.n) {
+        unsigned long long keep = 0;
+        for (int t = 0; t < 64; t++) {
+          const int h = t >> 5, i = (t >> 4) & 1, r = t & 15;
+          if (g * WAVE + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h < cb.n) keep |= 1ull << t;
+        }
+        mask &= keep;
+      }
+    }
+    const unsigned n = __popcll(mask);
+    if (__ballot(n != 0) == 0) continue;                 // wave-uniform
+    // wave-aggregated reservation in the pair list
+    unsigned pre = n;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const unsigned v = __shfl_up(pre, off, WAVE);
+      if (lane >= off) pre += v;
+    }
+    const unsigned wave_total = __shfl(pre, WAVE - 1, WAVE);
+    unsigned base = 0;
+    if (lane == 0) {
+      base = atomicAdd(col_count + blockIdx.x, wave_total);
+      if (base + wave_total > cap_col) atomicMax(pair_count, cap + 1);
+    }
+    base = __shfl(base, 0, WAVE) + pre - n;
+    if (n) {
+      ngr++; nrow += n;
+      unsigned at = base;
+      unsigned long long mm = mask;
+      uint2 *seg = pairs + static_cast<size_t>(blockIdx.x) * cap_col;
+      while (mm) {
+        const int t = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        const int h = t >> 5, i = (t >> 4) & 1, r = t & 15;
+        if (at < cap_col)
+          seg[at] = make_uint2(static_cast<uint32_t>(b),
+                               static_cast<uint32_t>(g * WAVE + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h));
+        at++;
+      }
+    }
+  }
+  // statistics: groups re-ranked per sample (summed over the chunks through gcount), totals
+  s_cnt[gy][bx] = ngr;
+  __syncthreads();
+  if (gy == 0 && live) {
+    unsigned tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) tot += s_cnt[k][bx];
+    if (tot) {
+      const unsigned before = atomicAdd(gcount + b, tot);
+      atomicMax(col_count + gridDim.x * 3 + blockIdx.x, before + tot);      // per-column maximum
+    }
+  }
+  unsigned a0 = ngr, a1 = nrow;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { a0 += __shfl_xor(a0, off, WAVE); a1 += __shfl_xor(a1, off, WAVE); }
+  if (lane == 0 && a1) {                                                    // per-column totals; K2p folds them
+    atomicAdd(col_count + gridDim.x * 1 + blockIdx.x, a0);
+    atomicAdd(col_count + gridDim.x * 2 + blockIdx.x, a1);
+  }
+  (void)stats;
+}
+
+constexpr int PAIR_MAX_COLS = 4096;     // 32-sample columns per run (131 072 samples)
+
+__global__ __launch_bounds__(256) void k_rerank_pairs(CbView cb, const float *__restrict__ rows,
+                                                      int64_t n_rows, int64_t first, uint32_t cap,
+                                                      uint32_t cap_col, int ncols,
+                                                      const uint2 *__restrict__ pairs,
+                                                      const uint32_t *__restrict__ col_count,
+                                                      const uint32_t *__restrict__ pair_count,
+                                                      uint64_t *__restrict__ keys,
+                                                      unsigned long long *__restrict__ stats) {
+  // A fixed, small grid (workgroup launches cost ~50 ns each: a grid sized for the worst case was
+  // the whole cost of this kernel).  Every workgroup builds the same table of 256-entry chunks per
+  // column (prefix sums of the segment fills) and takes chunks round-robin.
+  __shared__ uint32_t s_pref[PAIR_MAX_COLS + 1];
+  __shared__ uint32_t s_scan[256];
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && *pair_count <= cap) {            // the columns' statistics, once
+    for (int c = tid; c < ncols; c += 256) {
+      const uint32_t g = col_count[ncols * 1 + c], r = col_count[ncols * 2 + c];
+      if (r) { atomicAdd(stats + 0, static_cast<unsigned long long>(g)); atomicAdd(stats + 1, static_cast<unsigned long long>(r)); }
+      atomicMax(stats + 2, static_cast<unsigned long long>(col_count[ncols * 3 + c]));
+    }
+  }
+  if (*pair_count > cap) return;                         // a segment overflowed: K2r does the whole run
+  const int per = (ncols + 255) / 256;
+  uint32_t mine = 0;
+  for (int c = tid * per; c < (tid + 1) * per && c < ncols; c++) mine += (col_count[c] + 255u) >> 8;
+  s_scan[tid] = mine;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  {
+    uint32_t run = s_scan[tid] - mine;                   // exclusive prefix of this thread's columns
+    for (int c = tid * per; c < (tid + 1) * per && c < ncols; c++) { s_pref[c] = run; run += (col_count[c] + 255u) >> 8; }
+    if (tid == 255) s_pref[ncols] = s_scan[255];
+  }
+  __syncthreads();
+  const uint32_t total = s_pref[ncols];
+  const bool vec = (cb.d & 3) == 0;
+  for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
+    int lo = 0, hi = ncols;                              // column with s_pref[col] <= id < s_pref[col + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[mid] <= id) lo = mid; else hi = mid; }
+    const uint32_t slot = (id - s_pref[lo]) * 256u + tid;
+    if (slot >= col_count[lo]) continue;
+    const uint2 pr = pairs[static_cast<size_t>(lo) * cap_col + slot];
+    const int64_t row = pr.y;
+    const float4 *crow = reinterpret_cast<const float4 *>(cb.tiles) + ((row >> 6) * cb.d4) * WAVE + (row & 63);
+    const float *x = rows + ((first + pr.x) % n_rows) * cb.d;
+    float acc = 0.0f;
+    // 8 chunks of the row and of the sample in flight per lane (independent loads first)
+    constexpr int UP = 8;
+    int q = 0;
+    for (; q + UP <= cb.d4; q += UP) {
+      float4 cc[UP], xx[UP];
+#pragma unroll
+      for (int u = 0; u < UP; u++) {
+        cc[u] = crow[static_cast<int64_t>(q + u) * WAVE];
+        xx[u] = vec ? reinterpret_cast<const float4 *>(x)[q + u] : load_x4<false>(x, q + u, cb.d);
+      }
+#pragma unroll
+      for (int u = 0; u < UP; u++) {
+        acc = sq_acc(acc, cc[u].x, xx[u].x);
+        acc = sq_acc(acc, cc[u].y, xx[u].y);
+        acc = sq_acc(acc, cc[u].z, xx[u].z);
+        acc = sq_acc(acc, cc[u].w, xx[u].w);
+      }
+    }
+    for (; q < cb.d4; q++) {
+      const float4 c = crow[static_cast<int64_t>(q) * WAVE];
+      const float4 xv = vec ? reinterpret_cast<const float4 *>(x)[q] : load_x4<false>(x, q, cb.d);
+      acc = sq_acc(acc, c.x, xv.x);
+      acc = sq_acc(acc, c.y, xv.y);
+      acc = sq_acc(acc, c.z, xv.z);
+      acc = sq_acc(acc, c.w, xv.w);
+    }
+    const uint64_t k = make_key(acc, unit_of_row(cb, row));
+    atomicMin(reinterpret_cast<unsigned long long *>(keys + pr.x), static_cast<unsigned long long>(k));
+  }
+}
+
+}  // namespace somhip

@@ -1,0 +1,326 @@
+// kernels/som_update.hpp -- K4a-K4: members, launch order, in-order mini-batch update
+// (part of kernels.hpp; see the notes at the top of that file)
+#pragma once
+#include "scan_masked.hpp"
+
+namespace somhip {
+
+// =====================================================================================
+// K4a: winners of a run -> lattice coordinates.  bxy[b] = (bx, by) of iteration b's
+// best-matching unit (som_rout.c:641-642), from its key or its fixed point
+// (som_rout.c:628-632); bx = -1 when the iteration teaches nothing (skipped sample, or
+// no row beat FLT_MAX).
+// =====================================================================================
+__global__ void k_decode_winners(const uint64_t *__restrict__ keys, const StepScalars *__restrict__ sc,
+                                 int64_t count, int xdim, int2 *__restrict__ bxy) {
+  int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (b >= count) return;
+  const StepScalars s = sc[b];
+  int2 o = make_int2(-1, -1);
+  if (s.reach >= 0) {
+    uint32_t widx = 0xFFFFFFFFu;
+    if (s.fixed >= 0) widx = static_cast<uint32_t>(s.fixed);
+    else {
+      uint64_t k = keys[b];
+      if (static_cast<uint32_t>(k >> 32) < FLT_MAX_BITS) widx = static_cast<uint32_t>(k);
+    }
+    if (widx != 0xFFFFFFFFu) o = make_int2(static_cast<int>(widx % static_cast<uint32_t>(xdim)),
+                                           static_cast<int>(widx / static_cast<uint32_t>(xdim)));
+  }
+  bxy[b] = o;
+}
+
+// =====================================================================================
+// K4b: who updates whom.  For every row group (64 code rows) the samples of the run whose
+// neighbourhood reaches it, in iteration order, each with the 64-bit mask of the member
+// rows: hexa_dist/rect_dist <= radius (som_rout.c:496) decided per (row, sample) with the
+// exact lattice arithmetic, after a cheap reach test on lattice rows.  One workgroup per
+// row group, one thread per sample (256 at a time), ordered compaction by ballot/prefix.
+// Gaussian neighbourhoods touch every row, so their list is every taught sample.
+//   cnt[g]                 number of entries
+//   ent[g*count + k]       {sample index in the run, member mask}
+// =====================================================================================
+struct MemberEntry { uint32_t sample; float alpha; unsigned long long mask; };   // alpha: the iteration's rate
+
+template <bool GAUSS>
+__global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
+                                                     const int2 *__restrict__ bxy,
+                                                     const uint64_t *__restrict__ keys,
+                                                     const StepScalars *__restrict__ sc,
+                                                     uint32_t *__restrict__ cnt,
+                                                     MemberEntry *__restrict__ ent,
+                                                     unsigned long long *__restrict__ stats) {
+  __shared__ uint32_t s_wcount[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t g = blockIdx.x;
+  const uint32_t xdim = static_cast<uint32_t>(cb.xdim);
+  const int64_t r0 = g * WAVE;
+  const int64_t r_last = (r0 + WAVE < cb.n ? r0 + WAVE : cb.n) - 1;
+  const int nlive = static_cast<int>(r_last - r0 + 1);
+  int g_tx0, g_ty0, g_txl, g_ty1;
+  txty_of_row(cb, r0, g_tx0, g_ty0);
+  txty_of_row(cb, r_last, g_txl, g_ty1);
+  // x extent of the group's units: a patch is 8 wide; a linear group inside one map row spans
+  // [first, last]; one that wraps covers everything
+  const int g_tx1 = cb.patch_w ? g_tx0 + 7 : (g_ty0 == g_ty1 ? g_txl : static_cast<int>(xdim) - 1);
+  const int g_txa = cb.patch_w ? g_tx0 : (g_ty0 == g_ty1 ? g_tx0 : 0);
+  const bool small_map = cb.xdim <= 1024 && g_ty1 < 1024;
+  const unsigned long long live_mask = nlive >= 64 ? ~0ull : ((1ull << nlive) - 1);
+  MemberEntry *out = ent + g * count;
+  uint32_t base = 0;
+  unsigned long long rows_total = 0, pairs_total = 0;
+
+  constexpr int RR = 4;                 // samples per thread and trip: their loads are issued together
+  for (int64_t b0 = 0; b0 < count; b0 += 256 * RR) {
+    unsigned long long mm[RR];
+    float al[RR];
+#pragma unroll
+    for (int r = 0; r < RR; r++) {
+      const int64_t b = b0 + 256 * r + tid;
+      unsigned long long m = 0;
+      float alpha_b = 0.f;
+      if (b < count) {
+      const StepScalars s = sc[b];
+      int2 w;
+      if (keys) {                                        // winners decoded here (K4a's rule), no extra launch
+        w = make_int2(-1, -1);
+        if (s.reach >= 0) {
+          uint32_t widx = 0xFFFFFFFFu;
+          if (s.fixed >= 0) widx = static_cast<uint32_t>(s.fixed);
+          else { const uint64_t k = keys[b]; if (static_cast<uint32_t>(k >> 32) < FLT_MAX_BITS) widx = static_cast<uint32_t>(k); }
+          if (widx != 0xFFFFFFFFu) w = make_int2(static_cast<int>(widx % xdim), static_cast<int>(widx / xdim));
+        }
+      } else {
+        w = bxy[b];
+      }
+      alpha_b = s.alpha;
+      // reach (rows) >= radius/0.866 + 1 also bounds the x extent (unit spacing 1, half-unit shifts)
+      if (w.x >= 0 && w.y + s.reach >= g_ty0 && w.y - s.reach <= g_ty1 &&
+          (GAUSS || (w.x + s.reach >= g_txa && w.x - s.reach <= g_tx1))) {
+        if (GAUSS) m = live_mask;
+        else if (cb.patch_w && small_map) {
+          // 8x8 patch, exact integer form: with every lattice quantity a multiple of 1/4,
+          //   lattice_sq <= thresh  <=>  (2dx)^2 + 3 dy^2 <= floor(4 thresh)   (hexa)
+          //                              dx^2 + dy^2     <= floor(thresh)     (rect)
+          // and in one lattice row the members are a contiguous run of tx.
+          const bool rect = cb.topol == 4;
+          const int K = static_cast<int>(floor(static_cast<double>(s.thresh) * (rect ? 1.0 : 4.0)));
+          if (K >= 0) {
+#pragma unroll
+            for (int iy = 0; iy < 8; iy++) {
+              const int ty = g_ty0 + iy, dy = w.y - ty;
+              const int rem = K - (rect ? dy * dy : 3 * dy * dy);
+              if (rem < 0) continue;
+              int W = static_cast<int>(sqrtf(static_cast<float>(rem)));      // integer sqrt, corrected
+              while ((W + 1) * (W + 1) <= rem) W++;
+              while (W * W > rem) W--;
+              // rect: |bx - tx| <= W.  hexa: |2(bx - tx) + o| <= W, o = 0 on same-parity rows,
+              // -1 when by is even, +1 when by is odd (som_rout.c:440-447)
+              int lo, hi;
+              if (rect) { lo = w.x - W; hi = w.x + W; }
+              else {
+                const int o = (dy & 1) ? ((w.y & 1) ? 1 : -1) : 0;
+                // 2 bx + o - W <= 2 tx <= 2 bx + o + W
+                const int a = 2 * w.x + o - W, b = 2 * w.x + o + W;
+                lo = (a + (a >= 0 ? 1 : 0)) / 2; if (2 * lo < a) lo++;      // ceil(a / 2)
+                hi = b >= 0 ? b / 2 : -((-b + 1) / 2);                       // floor(b / 2)
+              }
+              lo = lo < g_tx0 ? g_tx0 : lo;
+              hi = hi > g_tx0 + 7 ? g_tx0 + 7 : hi;
+              if (lo <= hi) {
+                const unsigned long long run = ((1ull << (hi - lo + 1)) - 1) << (lo - g_tx0);
+                m |= run << (8 * iy);
+              }
+            }
+          }
+        } else if (cb.patch_w) {
+          for (int u = 0; u < 64; u++) {                 // maps wider than 1024: per-unit test
+            const int tx = g_tx0 + (u & 7), ty = g_ty0 + (u >> 3);
+            if (lattice_sq(cb.topol, w.x, w.y, tx, ty) <= s.thresh) m |= 1ull << u;
+          }
+        } else {
+          int tx = g_tx0, ty = g_ty0;
+          for (int u = 0; u < nlive; u++) {
+            const float lsq = small_map ? lattice_sq_small(cb.topol, w.x, w.y, tx, ty)
+                                        : lattice_sq(cb.topol, w.x, w.y, tx, ty);
+            if (lsq <= s.thresh) m |= 1ull << u;
+            if (++tx == static_cast<int>(xdim)) { tx = 0; ty++; }
+          }
+        }
+      }
+    }
+      mm[r] = m;
+      al[r] = alpha_b;
+    }
+#pragma unroll
+    for (int r = 0; r < RR; r++) {
+      if (b0 + 256 * r >= count) break;                 // uniform
+      const int64_t b = b0 + 256 * r + tid;
+      const unsigned long long m = mm[r];
+      const bool on = m != 0;
+      const unsigned long long bal = __ballot(on);
+      if (lane == 0) s_wcount[wave] = __popcll(bal);
+      __syncthreads();
+      uint32_t off = base;
+      for (int w2 = 0; w2 < wave; w2++) off += s_wcount[w2];
+      if (on) {
+        MemberEntry e;
+        e.sample = static_cast<uint32_t>(b); e.alpha = al[r]; e.mask = m;
+        out[off + __popcll(bal & ((1ull << lane) - 1))] = e;
+        rows_total += __popcll(m);
+        pairs_total += 1;
+      }
+      base += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+      __syncthreads();
+    }
+  }
+  if (tid == 0) cnt[g] = base;
+  // instrumentation: (row, iteration) updates and (row group, iteration) pairs of this run
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    rows_total += __shfl_xor(rows_total, off, WAVE);
+    pairs_total += __shfl_xor(pairs_total, off, WAVE);
+  }
+  if (lane == 0 && stats) {     // 64 counter pairs (summed by the host): one pair took ~8 000 same-address atomics
+    unsigned long long *st = stats + 8 + 2 * (g & 63);
+    if (rows_total) atomicAdd(st, rows_total);
+    if (pairs_total) atomicAdd(st + 1, pairs_total);
+  }
+}
+
+// K4c: launch order for K4 -- row groups by member count, heaviest first, so the long
+// workgroups start early and the tail of the launch is made of short ones (rank by counting;
+// ties by index).  order[rank] = group.
+__global__ __launch_bounds__(256) void k_order_groups(const uint32_t *__restrict__ cnt, int ngroups,
+                                                      uint32_t *__restrict__ order) {
+  __shared__ uint32_t s_cnt[8192];                     // host guarantees ngroups <= 8192
+  for (int k = threadIdx.x; k < ngroups; k += blockDim.x) s_cnt[k] = cnt[k];
+  __syncthreads();
+  // 8 lanes share one group's ranking (an eighth of the comparisons each)
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = t >> 3, part = t & 7;
+  const bool live = g < ngroups;
+  const uint32_t mine = live ? s_cnt[g] : 0u;
+  uint32_t rank = 0;
+  if (live)
+    for (int k = part; k < ngroups; k += 8) {
+      const uint32_t c = s_cnt[k];
+      rank += (c > mine) || (c == mine && k < g);
+    }
+  rank += __shfl_xor(rank, 1, WAVE);
+  rank += __shfl_xor(rank, 2, WAVE);
+  rank += __shfl_xor(rank, 4, WAVE);
+  if (live && part == 0) order[rank] = static_cast<uint32_t>(g);
+}
+
+// =====================================================================================
+// K4: in-order neighbourhood update of a run of samples, driven by K4b's member lists.
+//
+// bubble_adapt (som_rout.c:472-506) / gaussian_adapt (:511-549) + adapt_vector
+// (lvq_pak.c:339-351) for iterations batch_start .. batch_start+count-1, applied to
+// every code row in iteration order.  One lane = one code row, QW chunks (4*QW dims) of
+// it held in registers across the whole run, so each touched row is read and written
+// once per run whatever the batch size.  A workgroup = ONE row group x 4 consecutive dim
+// slices (one per wave): the four waves see the same member list, so they stay balanced
+// between barriers.  The list is walked in tiles of TB entries: entry scalars -> LDS, the
+// tile's sample slices staged into LDS (one coalesced pass), then every wave applies the
+// tile's updates in order (member lanes from the entry's mask, x as broadcast reads).
+// =====================================================================================
+template <int QW, int TB, bool GAUSS, bool MASKED>
+__global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *__restrict__ rows,
+                                                        const uint8_t *__restrict__ mask,
+                                                        int64_t n_rows, int64_t data_first,
+                                                        int64_t count,
+                                                        const int2 *__restrict__ bxy,
+                                                        const StepScalars *__restrict__ sc,
+                                                        const uint32_t *__restrict__ cnt,
+                                                        const MemberEntry *__restrict__ ent,
+                                                        const uint32_t *__restrict__ order) {
+  constexpr int BQ = 4 * QW;                          // chunks per workgroup
+  __shared__ float4 xs[TB][BQ];
+  __shared__ uint32_t ms[MASKED ? TB : 1][MASKED ? BQ : 1];   // 4 mask bits per chunk
+  __shared__ float s_ga[GAUSS ? TB : 1][GAUSS ? WAVE : 1];    // gaussian: per-lane alpha
+  __shared__ unsigned long long s_mask[TB];
+  __shared__ long long s_xoff[TB];
+  __shared__ float s_alpha[TB], s_thr[TB];
+  __shared__ int s_bx[TB], s_by[TB];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t g = order ? order[blockIdx.x] : blockIdx.x;     // heaviest groups first
+  const uint32_t n_ent = cnt[g];
+  if (n_ent == 0) return;                             // nothing in this run touches the group
+  const int qblk = blockIdx.y * BQ;
+  const int q0 = qblk + wave * QW;
+  const bool vec = (cb.d & 3) == 0;
+  const MemberEntry *list = ent + g * count;
+  int tx, ty;
+  txty_of_row(cb, g * WAVE + lane, tx, ty);
+
+  float4 c[QW];
+#pragma unroll
+  for (int j = 0; j < QW; j++)
+    c[j] = (q0 + j < cb.d4) ? *tile_ptr(cb, g, q0 + j, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (uint32_t k0 = 0; k0 < n_ent; k0 += TB) {
+    const int tb = static_cast<int>(n_ent - k0 < TB ? n_ent - k0 : TB);
+    // ---- entry scalars
+    if (tid < tb) {
+      const MemberEntry e = list[k0 + tid];
+      const StepScalars s = sc[e.sample];
+      s_mask[tid] = e.mask;
+      s_alpha[tid] = s.alpha;
+      s_xoff[tid] = ((data_first + e.sample) % n_rows) * cb.d;
+      if (GAUSS) { const int2 w = bxy[e.sample]; s_bx[tid] = w.x; s_by[tid] = w.y; s_thr[tid] = s.thresh; }
+    }
+    __syncthreads();
+    // ---- sample slices -> LDS (+ gaussian: per-lane alpha, once per workgroup)
+    for (int e = tid; e < tb * BQ; e += 256) {
+      const int i = e / BQ, j = e % BQ, q = qblk + j;
+      if (q < cb.d4) {
+        const long long xo = s_xoff[i];
+        const float *xr = rows + xo;
+        xs[i][j] = vec ? reinterpret_cast<const float4 *>(xr)[q] : load_x4<false>(xr, q, cb.d);
+        if (MASKED) {
+          const uint8_t *mk = mask + xo;
+          uint32_t mm = 0;
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (q * 4 + u >= cb.d || mk[q * 4 + u] != 0) mm |= 1u << u;
+          ms[i][j] = mm;
+        }
+      }
+    }
+    if (GAUSS) {
+      for (int i = wave; i < tb; i += 4)
+        s_ga[i][lane] = gaussian_alpha(lattice_sq(cb.topol, s_bx[i], s_by[i], tx, ty), s_thr[i], s_alpha[i]);
+    }
+    __syncthreads();
+    // ---- the tile's updates, in iteration order
+    if (q0 < cb.d4) {
+      for (int i = 0; i < tb; i++) {
+        if ((s_mask[i] >> lane) & 1ull) {
+          const float a = GAUSS ? s_ga[i][lane] : s_alpha[i];
+#pragma unroll
+          for (int j = 0; j < QW; j++) {
+            const float4 n = adapt4(c[j], xs[i][wave * QW + j], a);
+            if (MASKED) {
+              const uint32_t mm = ms[i][wave * QW + j];
+              if (!(mm & 1u)) c[j].x = n.x;
+              if (!(mm & 2u)) c[j].y = n.y;
+              if (!(mm & 4u)) c[j].z = n.z;
+              if (!(mm & 8u)) c[j].w = n.w;
+            } else {
+              c[j] = n;      // padding dims: x pad = 0, c pad = 0 -> stays 0
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < QW; j++)
+    if (q0 + j < cb.d4) *tile_ptr_w(cb, g, q0 + j, lane) = c[j];
+}
+
+}  // namespace somhip
