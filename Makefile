@@ -15,7 +15,7 @@ LIB       = som_lvq_pak_amd/libsomhip.so
 all: lib oracle tools
 
 lib: $(LIB)
-KHDR      = $(CSRC)/kernels.hpp $(wildcard $(CSRC)/kernels/*.hpp)
+KHDR      = $(CSRC)/kernels.hpp $(wildcard $(CSRC)/kernels/*.hpp) $(wildcard $(CSRC)/host_*.inc)
 $(LIB): $(CSRC)/somhip.hip $(KHDR) $(CSRC)/schedule.hpp include/somhip.h Makefile
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/somhip.hip
 
