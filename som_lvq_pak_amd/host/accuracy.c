@@ -20,16 +20,9 @@ int main(int argc, char **argv)
   char *out_file = extract_parameter(argc, argv, "-cfout", OPTION);
   char *funcname = extract_parameter(argc, argv, "-selfuncs", OPTION);
 
-  ifverbose(2) fprintf(stderr, "Input entries are read from file %s\n", in_data_file);
-  struct entries *data = open_entries(in_data_file, 1, 1);
-  if (!data) { fprintf(stderr, "Can't open data file '%s'\n", in_data_file); exit(1); }
-  ifverbose(2) fprintf(stderr, "Codebook entries are read from file %s\n", in_code_file);
-  struct entries *codes = open_entries(in_code_file, 1, 1);
-  if (!codes) { fprintf(stderr, "Can't open code file '%s'\n", in_code_file); close_entries(data); exit(1); }
-  if (data->dimension != codes->dimension) {
-    fprintf(stderr, "Data and codebook vectors have different dimensions");
-    close_entries(data); close_entries(codes); exit(1);
-  }
+  struct pak_inputs io;
+  if (pak_open_inputs(in_data_file, 1, "Can't open data file '%s'\n", in_code_file, 1, "Can't open code file '%s'\n", 0, &io)) exit(1);
+  struct entries *data = io.data, *codes = io.codes;
   FILE *ocf = NULL;
   if (out_file && !(ocf = fopen(out_file, "w"))) { fprintf(stderr, "can't open file '%s'\n", out_file); exit(1); }
   set_teach_params(&teach, codes, data, funcname);

@@ -148,6 +148,24 @@ unsigned char *knn_correct_all(struct entries *data, int knn);
 struct entries *pick_rows(struct entries *src, const long *rows, long n);
 struct entries *lininit_codes(struct entries *data, int topol, int neigh, int xdim, int ydim);
 struct entries *randinit_codes(struct entries *data, int topol, int neigh, int xdim, int ydim);
+/* ---- what every tool does before the engine is involved ---- */
+struct pak_inputs { struct entries *data, *codes; };
+/* opens -din then -cin with the reference's messages; fmt strings take the file name.  need_map:
+ * the codebook must be a hexa/rect map.  Returns 0 or 1 (after closing what it opened). */
+int pak_open_inputs(const char *din, int data_labels, const char *data_fail_fmt, const char *cin, int code_labels,
+                    const char *code_fail_fmt, int need_map, struct pak_inputs *io);
+/* options shared by the training tools: -din -cin -cout -rlen -rand -buffer -alpha_type -selfuncs
+ * -snapfile -snapinterval (vsom.c:77-131, lvqtrain.c:115-142) */
+struct pak_train_cli {
+  char *din, *cin, *cout, *rand_s, *alpha_s, *funcname;
+  long length, buffer;
+  struct snapshot_info snap;
+  int want_snapshots;
+};
+void pak_train_cli(int argc, char **argv, struct pak_train_cli *o);
+/* init_random(-rand) and the data order it asks for: one shuffle of the whole file, or per-buffer
+ * reshuffling when -buffer is smaller than the file (datafile.c:237-344) */
+void pak_apply_rand(struct entries *data, const char *rand_s, long buffer);
 void pak_shutdown(void);
 
 #endif

@@ -474,6 +474,57 @@ ALPHA_FUNC *alpha_func_by_name(const char *name, short *id)
   return NULL;
 }
 
+/* ------------------------------------------------------------------ shared tool front end */
+int pak_open_inputs(const char *din, int data_labels, const char *data_fail_fmt, const char *cin, int code_labels,
+                    const char *code_fail_fmt, int need_map, struct pak_inputs *io)
+{
+  io->data = io->codes = NULL;
+  ifverbose(2) fprintf(stderr, "Input entries are read from file %s\n", din);
+  if (!(io->data = open_entries(din, data_labels, 1))) { fprintf(stderr, data_fail_fmt, din); return 1; }
+  ifverbose(2) fprintf(stderr, "Codebook entries are read from file %s\n", cin);
+  if (!(io->codes = open_entries(cin, code_labels, 1))) { fprintf(stderr, code_fail_fmt, cin); goto bad; }
+  if (need_map && io->codes->topol < TOPOL_HEXA) { fprintf(stderr, "File %s is not a map file\n", cin); goto bad; }
+  if (io->data->dimension != io->codes->dimension) {
+    fprintf(stderr, need_map == 2 ? "Data and codebook vectors have different dimensions (%d != %d)"
+                                  : "Data and codebook vectors have different dimensions",
+            io->data->dimension, io->codes->dimension);
+    goto bad;
+  }
+  return 0;
+bad:
+  close_entries(io->data); close_entries(io->codes);
+  io->data = io->codes = NULL;
+  return 1;
+}
+
+void pak_train_cli(int argc, char **argv, struct pak_train_cli *o)
+{
+  memset(o, 0, sizeof *o);
+  o->din = extract_parameter(argc, argv, "-din", ALWAYS);
+  o->cin = extract_parameter(argc, argv, "-cin", ALWAYS);
+  o->cout = extract_parameter(argc, argv, "-cout", ALWAYS);
+  o->length = oatoi(extract_parameter(argc, argv, "-rlen", ALWAYS), 1);
+  o->rand_s = extract_parameter(argc, argv, "-rand", OPTION);
+  o->buffer = oatoi(extract_parameter(argc, argv, "-buffer", OPTION), 0);
+  o->alpha_s = extract_parameter(argc, argv, "-alpha_type", OPTION);
+  o->funcname = extract_parameter(argc, argv, "-selfuncs", OPTION);
+  o->snap.filename = extract_parameter(argc, argv, "-snapfile", OPTION);
+  o->snap.interval = oatoi(extract_parameter(argc, argv, "-snapinterval", OPTION), 0);
+  o->want_snapshots = o->snap.interval != 0;
+  if (o->want_snapshots && !o->snap.filename) {
+    o->snap.filename = o->cout;
+    fprintf(stderr, "snapshot file not specified, using '%s'", o->snap.filename);
+  }
+}
+
+void pak_apply_rand(struct entries *data, const char *rand_s, long buffer)
+{
+  init_random((int)oatoi(rand_s, 0));
+  if (!rand_s) return;
+  if (buffer > 0 && buffer < data->num_entries) { data->buffer = buffer; data->random_order = 1; }   /* reshuffled per buffer */
+  else randomize_entry_order(data);                                                               /* once, at load */
+}
+
 /* ------------------------------------------------------------------ the HIP back end */
 static somhip_engine *g_engine = NULL;
 

@@ -22,20 +22,9 @@ int main(int argc, char **argv)
   char *funcname = extract_parameter(argc, argv, "-selfuncs", OPTION);
   if (numlabs < 0) numlabs = 0;
 
-  ifverbose(2) fprintf(stderr, "Input entries are read from file %s\n", in_data_file);
-  struct entries *data = open_entries(in_data_file, 0, 1);
-  if (!data) { fprintf(stderr, "Can't open data file '%s'\n", in_data_file); exit(1); }
-  ifverbose(2) fprintf(stderr, "Codebook entries are read from file %s\n", in_code_file);
-  struct entries *codes = open_entries(in_code_file, 0, 1);
-  if (!codes) { fprintf(stderr, "Can't open code file '%s'\n", in_code_file); close_entries(data); exit(1); }
-  if (codes->topol < TOPOL_HEXA) {
-    fprintf(stderr, "File %s is not a map file\n", in_code_file);
-    close_entries(data); close_entries(codes); exit(1);
-  }
-  if (data->dimension != codes->dimension) {
-    fprintf(stderr, "Data and codebook vectors have different dimensions");
-    close_entries(data); close_entries(codes); exit(1);
-  }
+  struct pak_inputs io;
+  if (pak_open_inputs(in_data_file, 0, "Can't open data file '%s'\n", in_code_file, 0, "Can't open code file '%s'\n", 1, &io)) exit(1);
+  struct entries *data = io.data, *codes = io.codes;
   set_teach_params(&teach, codes, data, funcname);
 
   long n = data->num_entries, noc = codes->num_entries;

@@ -9,110 +9,102 @@
 #include <strings.h>
 #include "pak.h"
 
-static long get_int(const char *q, long no)
+/* the fourteen questions, in the reference's order; answers as text (an empty stdin gives "") */
+enum { Q_TRIALS, Q_DATA, Q_TEST, Q_OUT, Q_TOPOL, Q_NEIGH, Q_XDIM, Q_YDIM, Q_LEN1, Q_ALPHA1, Q_RADIUS1, Q_LEN2, Q_ALPHA2,
+       Q_RADIUS2, Q_COUNT };
+static const struct { const char *text; int is_name; } questions[Q_COUNT] = {
+    {"Give the number of trials", 0},           {"Give the input data file name", 1},
+    {"Give the input test file name", 1},       {"Give the output map file name", 1},
+    {"Give the topology type", 1},              {"Give the neighborhood type", 1},
+    {"Give the x-dimension", 0},                {"Give the y-dimension", 0},
+    {"Give the training length of first part", 0},  {"Give the training rate of first part", 0},
+    {"Give the radius in first part", 0},       {"Give the training length of second part", 0},
+    {"Give the training rate of second part", 0},   {"Give the radius in second part", 0}};
+
+static void ask(char answers[Q_COUNT][100])
 {
-  char str[100];
-  printf("%s: ", q);
-  if (!fgets(str, sizeof str, stdin)) return no;
-  return oatoi(str, no);
+  for (int q = 0; q < Q_COUNT; q++) {
+    printf("%s: ", questions[q].text);
+    if (!fgets(answers[q], 100, stdin)) {
+      if (questions[q].is_name) { printf("Can't read required data\n"); exit(1); }
+      answers[q][0] = '\0';
+      continue;
+    }
+    if (questions[q].is_name) answers[q][strcspn(answers[q], " \n")] = '\0';
+  }
 }
-static float get_float(const char *q, float no)
-{
-  char str[100];
-  printf("%s: ", q);
-  if (!fgets(str, sizeof str, stdin)) return no;
-  return (float)atof(str);
-}
-static char *get_str(const char *q)
-{
-  char str[100];
-  printf("%s: ", q);
-  if (!fgets(str, sizeof str, stdin)) { printf("Can't read required data\n"); exit(1); }
-  char *t = strdup(str), *e;
-  if ((e = strchr(t, ' '))) *e = '\0';
-  if ((e = strchr(t, '\n'))) *e = '\0';
-  return t;
-}
+static long as_long(const char *a) { return *a ? atol(a) : 0; }
+static float as_float(const char *a) { return *a ? (float)atof(a) : 0.0f; }
 
 int main(int argc, char **argv)
 {
   struct teach_params params;
+  char ans[Q_COUNT][100];
   memset(&params, 0, sizeof params);
   global_options(argc, argv);
   printf("vfind (MI355X engine): trains a number of randomly initialised maps in two parts each\n"
          "(ordering, fine tuning) and saves the one with the smallest quantization error on the\n"
          "test file.  Answer the questions below; training starts after the last one.\n\n");
-  long not = get_int("Give the number of trials", 0);
-  char *in_data_file = get_str("Give the input data file name");
-  char *in_test_file = get_str("Give the input test file name");
-  char *out_code_file = get_str("Give the output map file name");
-  char *s = get_str("Give the topology type");
-  int topol = !strcasecmp(s, "hexa") ? TOPOL_HEXA : !strcasecmp(s, "rect") ? TOPOL_RECT : TOPOL_UNKNOWN;
-  if (topol == TOPOL_UNKNOWN) { ifverbose(2) fprintf(stderr, "Unknown topology type, using hexagonal\n"); topol = TOPOL_HEXA; }
-  s = get_str("Give the neighborhood type");
-  int neigh = !strcasecmp(s, "bubble") ? NEIGH_BUBBLE : !strcasecmp(s, "gaussian") ? NEIGH_GAUSSIAN : NEIGH_UNKNOWN;
-  if (neigh == NEIGH_UNKNOWN) { ifverbose(2) fprintf(stderr, "Unknown neighborhood type, using bubble\n"); neigh = NEIGH_BUBBLE; }
-  int xdim = (int)get_int("Give the x-dimension", 0);
-  int ydim = (int)get_int("Give the y-dimension", 0);
-  long length1 = get_int("Give the training length of first part", 0);
-  float alpha1 = get_float("Give the training rate of first part", 0.0);
-  float radius1 = get_float("Give the radius in first part", 0.0);
-  long length2 = get_int("Give the training length of second part", 0);
-  float alpha2 = get_float("Give the training rate of second part", 0.0);
-  float radius2 = get_float("Give the radius in second part", 0.0);
+  ask(ans);
   printf("\n");
+  long trials = as_long(ans[Q_TRIALS]);
+  int topol = !strcasecmp(ans[Q_TOPOL], "hexa") ? TOPOL_HEXA : !strcasecmp(ans[Q_TOPOL], "rect") ? TOPOL_RECT : TOPOL_UNKNOWN;
+  if (topol == TOPOL_UNKNOWN) { ifverbose(2) fprintf(stderr, "Unknown topology type, using hexagonal\n"); topol = TOPOL_HEXA; }
+  int neigh = !strcasecmp(ans[Q_NEIGH], "bubble") ? NEIGH_BUBBLE : !strcasecmp(ans[Q_NEIGH], "gaussian") ? NEIGH_GAUSSIAN : NEIGH_UNKNOWN;
+  if (neigh == NEIGH_UNKNOWN) { ifverbose(2) fprintf(stderr, "Unknown neighborhood type, using bubble\n"); neigh = NEIGH_BUBBLE; }
+  int xdim = (int)as_long(ans[Q_XDIM]), ydim = (int)as_long(ans[Q_YDIM]);
+  const struct { long length; float alpha, radius; const char *what; } part[2] = {
+      {as_long(ans[Q_LEN1]), as_float(ans[Q_ALPHA1]), as_float(ans[Q_RADIUS1]), "first"},
+      {as_long(ans[Q_LEN2]), as_float(ans[Q_ALPHA2]), as_float(ans[Q_RADIUS2]), "second"}};
+
   use_fixed_level = (int)oatoi(extract_parameter(argc, argv, "-fixed", OPTION), 0);
   use_weights_level = (int)oatoi(extract_parameter(argc, argv, "-weights", OPTION), 0);
   char *alpha_s = extract_parameter(argc, argv, "-alpha_type", OPTION);
-  int qmode = (int)oatoi(extract_parameter(argc, argv, "-qetype", OPTION), 0);
+  int weighted_error = oatoi(extract_parameter(argc, argv, "-qetype", OPTION), 0) > 0;
   char *funcname = extract_parameter(argc, argv, "-selfuncs", OPTION);
 
-  int error = 0;
+  int error = 1;
   struct entries *data = NULL, *testdata = NULL, *best = NULL;
-  ifverbose(2) fprintf(stderr, "Input entries are read from file %s\n", in_data_file);
-  if (!(data = open_entries(in_data_file, 0, 1))) { fprintf(stderr, "Can't open data file '%s'\n", in_data_file); error = 1; goto end; }
-  ifverbose(2) fprintf(stderr, "Test entries are read from file %s\n", in_test_file);
-  if (!(testdata = open_entries(in_test_file, 0, 1))) { fprintf(stderr, "Can't open test data file '%s'\n", in_test_file); error = 1; goto end; }
-  if ((long)xdim * ydim <= 0 || xdim < 0) { fprintf(stderr, "Dimensions of map (%d %d) are incorrect\n", xdim, ydim); error = 1; goto end; }
-  params.alpha_func = alpha_func_by_name(alpha_s ? alpha_s : "linear", &params.alpha_type);
-  if (!params.alpha_func) { fprintf(stderr, "Unknown alpha type %s\n", alpha_s); error = 1; goto end; }
+  ifverbose(2) fprintf(stderr, "Input entries are read from file %s\n", ans[Q_DATA]);
+  if (!(data = open_entries(ans[Q_DATA], 0, 1))) { fprintf(stderr, "Can't open data file '%s'\n", ans[Q_DATA]); goto end; }
+  ifverbose(2) fprintf(stderr, "Test entries are read from file %s\n", ans[Q_TEST]);
+  if (!(testdata = open_entries(ans[Q_TEST], 0, 1))) { fprintf(stderr, "Can't open test data file '%s'\n", ans[Q_TEST]); goto end; }
+  if ((long)xdim * ydim <= 0 || xdim < 0) { fprintf(stderr, "Dimensions of map (%d %d) are incorrect\n", xdim, ydim); goto end; }
+  short alpha_type;
+  ALPHA_FUNC *alpha_func = alpha_func_by_name(alpha_s ? alpha_s : "linear", &alpha_type);
+  if (!alpha_func) { fprintf(stderr, "Unknown alpha type %s\n", alpha_s); goto end; }
 
-  float qerrorb = FLT_MAX;
-  long bnot = 0, nod = 0;
-  while (not) {                                        /* vfind.c:244-306 */
-    init_random((int)not);
+  float best_error = FLT_MAX;
+  long best_seed = 0, nod = testdata->num_entries;
+  for (long seed = trials; seed > 0; seed--) {         /* vfind.c:244-306: the seed is the trial counter */
+    init_random((int)seed);
     ifverbose(2) fprintf(stderr, "Initializing codebook\n");
     struct entries *codes = randinit_codes(data, topol, neigh, xdim, ydim);
-    short at = params.alpha_type;
-    ALPHA_FUNC *af = params.alpha_func;
     set_teach_params(&params, codes, NULL, funcname);
-    params.alpha_type = at; params.alpha_func = af;
+    params.alpha_type = alpha_type; params.alpha_func = alpha_func;
     set_som_params(&params);
     params.data = data;
-    params.length = length1; params.alpha = alpha1; params.radius = radius1;
-    ifverbose(2) fprintf(stderr, "Training map, first part, rlen: %ld alpha: %f\n", params.length, params.alpha);
-    if (!som_training(&params)) { error = 1; goto end; }
-    params.length = length2; params.alpha = alpha2; params.radius = radius2;
-    ifverbose(2) fprintf(stderr, "Training map, second part, rlen: %ld alpha: %f\n", params.length, params.alpha);
-    if (!som_training(&params)) { error = 1; goto end; }
-    params.data = testdata;
+    for (int p = 0; p < 2; p++) {
+      params.length = part[p].length; params.alpha = part[p].alpha; params.radius = part[p].radius;
+      ifverbose(2) fprintf(stderr, "Training map, %s part, rlen: %ld alpha: %f\n", part[p].what, params.length, params.alpha);
+      if (!som_training(&params)) goto end;
+    }
+    params.data = testdata;                            /* radius of the second part stays for -qetype 1 */
     ifverbose(2) fprintf(stderr, "Calculating quantization error\n");
-    float qerror = qmode > 0 ? find_qerror2(&params) : find_qerror(&params);
-    nod = testdata->num_entries;
-    if (qerror < qerrorb) {
-      qerrorb = qerror;
-      bnot = not;
-      struct entries *tmp = best; best = codes; codes = tmp;
+    float qerror = weighted_error ? find_qerror2(&params) : find_qerror(&params);
+    if (qerror < best_error) {
+      best_error = qerror; best_seed = seed;
+      struct entries *old = best; best = codes; codes = old;
     }
     if (codes) close_entries(codes);
-    ifverbose(1) fprintf(stderr, "%3ld: %f\n", not, qerror / (float)nod);
-    not--;
+    ifverbose(1) fprintf(stderr, "%3ld: %f\n", seed, qerror / (float)nod);
   }
   if (best) {
-    ifverbose(2) fprintf(stdout, "Codebook entries are saved to file %s\n", out_code_file);
-    save_entries(best, out_code_file);
-    ifverbose(1) fprintf(stdout, "Smallest error with random seed %3ld: %f\n", bnot, qerrorb / (float)nod);
+    ifverbose(2) fprintf(stdout, "Codebook entries are saved to file %s\n", ans[Q_OUT]);
+    save_entries(best, ans[Q_OUT]);
+    ifverbose(1) fprintf(stdout, "Smallest error with random seed %3ld: %f\n", best_seed, best_error / (float)nod);
   }
+  error = 0;
 end:
   if (best) close_entries(best);
   if (data) close_entries(data);
