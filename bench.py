@@ -53,6 +53,8 @@ def parse():
                     help="winner-search implementation (all bit-identical); auto = the engine's default")
     ap.add_argument("--force-sharded-path", action="store_true",
                     help="N=1 only: drive the two-phase step from Python as the N>1 path does (host-overhead check)")
+    ap.add_argument("--shards", default="interleaved", choices=["interleaved", "contiguous"],
+                    help="N > 1: how the map's units are dealt to the ranks")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with ranks sharing GPUs (keys staged through the host)")
     ap.add_argument("--online-vectors", type=int, default=-1,
@@ -119,8 +121,17 @@ def main():
         eng.set_scan_mode(a.scan)
     ds = E.Dataset(eng, device_ptr=data.data_ptr(), n=nvec, dim=d)
     from som_lvq_pak_amd.sharded import shard_rows
-    r0, r1 = shard_rows(N, world, rank)
-    cb = E.Codebook(eng, init[r0:r1], E.TOPOL_HEXA, E.NEIGH_BUBBLE, xdim, ydim, row_offset=r0, n_global=N)
+    if a.shards == "interleaved" and world > 1 and xdim % 8 == 0 and ydim % 8 == 0:
+        # 8x8-unit patches dealt round-robin to the ranks: every rank sees every region of the map, so the
+        # neighbourhood updates of a batch are spread evenly whatever the radius (include/somhip.h)
+        mine = E.shard_units(xdim, ydim, rank, world, eng.lib)
+        cb = E.Codebook(eng, init[mine], E.TOPOL_HEXA, E.NEIGH_BUBBLE, xdim, ydim, interleave=(rank, world))
+        layout = "8x8-unit patches interleaved over %d ranks" % world
+    else:
+        r0, r1 = shard_rows(N, world, rank)
+        mine = np.arange(r0, r1)
+        cb = E.Codebook(eng, init[r0:r1], E.TOPOL_HEXA, E.NEIGH_BUBBLE, xdim, ydim, row_offset=r0, n_global=N)
+        layout = "contiguous row blocks /%d" % world
     lib = eng.lib
 
     from som_lvq_pak_amd import sharded
@@ -149,7 +160,7 @@ def main():
     for k in range(min(W, K)):
         step(k * B, k * B, B, max(W, 1) * B)
     eng.sync()
-    cb.upload(init[r0:r1])
+    cb.upload(init[mine])
 
     # ---- timed region: one complete training run of K*B vectors ----
     if world > 1:      # N > 1: steps are short; event only the two kernels the roofline lines need
@@ -189,7 +200,7 @@ def main():
     nonl = a.online_vectors if a.online_vectors >= 0 else (length if length <= 600000 else 0)
     if world == 1 and B > 1 and nonl > 0:
         nonl = min(nonl, length)
-        cb.upload(init[r0:r1])
+        cb.upload(init[mine])
         eng.sync()
         p = SomParams(length, a.alpha, radius, E.ALPHA_LINEAR, 0, 0, 1, 0, nonl, 0)
         t2 = time.perf_counter()
@@ -209,7 +220,7 @@ def main():
     if rank == 0:
         value = K * B / elapsed
         # rooflines of the kernels of the timed region; the dominant one (by total time) is reported
-        n_local = r1 - r0
+        n_local = len(mine)
         bpad = ((B + 31) // 32) * 32
         rows_upd = stats_after["row_updates"] - stats_before["row_updates"]
 
@@ -290,7 +301,7 @@ def main():
                        "dim": d, "codebook_rows": N, "batch": B, "vectors": K * B, "alpha": a.alpha,
                        "radius": radius, "alpha_type": "linear",
                        "schedule": "mini-batch (winners per batch, in-order updates)" if B > 1 else "online (reference-exact)",
-                       "parallelism": "codebook rows sharded /%d, all-reduce(MIN) of (dist,idx) keys" % world
+                       "parallelism": "codebook sharded (%s), all-reduce(MIN) of (dist,idx) keys" % layout
                        if world > 1 else "single GPU"},
             "roofline": roof,
             "roofline_other": roof_other,

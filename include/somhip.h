@@ -81,6 +81,18 @@ int  somhip_debug_prefilter(somhip_codebook *cb, somhip_dataset *ds, int64_t fir
 int  somhip_codebook_create(somhip_engine *e, const float *rows, const int32_t *labels,
                             int64_t n_rows, int dim, int topol, int neigh, int xdim, int ydim,
                             int64_t row_offset, int64_t n_global, somhip_codebook **out);
+/* Interleaved shards of a map (multi-GPU SOM training): the map is cut into 8x8-unit patches numbered
+ * row-major and shard s of S holds patches s, s+S, s+2S, ...  A neighbourhood (som_rout.c:472-549)
+ * of any radius around any winner then covers about 1/S of its units on every shard, so the update
+ * work of a batch is the same on all ranks; contiguous blocks of rows load the ranks that hold the
+ * middle of the map up to 1.4x the mean.  Map sides must be multiples of 8.
+ * somhip_shard_units: the global unit index (k of the comment above) of every row of the shard, in the
+ * order in which create_interleaved / download / upload exchange its rows (units == NULL: count only).
+ * Keys, traces and winners carry global unit indices as with contiguous shards. */
+int  somhip_shard_units(int xdim, int ydim, int shard_index, int shard_count, int64_t *units, int64_t *n_units);
+int  somhip_codebook_create_interleaved(somhip_engine *e, const float *rows, int64_t n_rows, int dim,
+                                        int topol, int neigh, int xdim, int ydim, int shard_index,
+                                        int shard_count, somhip_codebook **out);
 /* device -> host gather of the rows (what save_entries / save_snapshot need,
  * datafile.c:353, lvq_pak.c:665) */
 int  somhip_codebook_download(somhip_codebook *cb, float *rows);

@@ -49,6 +49,9 @@ SIGNATURES = {
     "somhip_codebook_create": (C.c_int, [C.c_void_p, c_float_p, c_i32_p, C.c_int64, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                          C.POINTER(C.c_void_p)]),
+    "somhip_shard_units": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_i64_p, c_i64_p]),
+    "somhip_codebook_create_interleaved": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                                     C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "somhip_codebook_download": (C.c_int, [C.c_void_p, c_float_p]),
     "somhip_codebook_upload": (C.c_int, [C.c_void_p, c_float_p]),
     "somhip_codebook_destroy": (None, [C.c_void_p]),

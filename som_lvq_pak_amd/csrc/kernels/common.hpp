@@ -25,14 +25,22 @@ struct CbView {
                         // map units, so a round neighbourhood fills whole wavefronts instead of
                         // slivers of 64x1 strips.  Maps only, sides multiple of 8, shards on 8-row
                         // boundaries; indices seen outside the engine are always unit indices.
+  int patch_stride;     // interleaved shards (patch order only): local patch p is map patch
+  int patch_phase;      //   p * patch_stride + patch_phase; a contiguous shard / whole map has (1, 0)
 };
 
 // global unit index (= the reference's row index, datafile.c:781,836) of local storage row `row`
-__device__ __forceinline__ uint32_t unit_of_row(const CbView &cb, int64_t row) {
+__host__ __device__ __forceinline__ uint32_t unit_of_row(const CbView &cb, int64_t row) {
   if (cb.patch_w == 0) return static_cast<uint32_t>(row + cb.row_offset);
-  const uint32_t p = static_cast<uint32_t>(row >> 6), i = static_cast<uint32_t>(row) & 63u;
+  const uint32_t p = static_cast<uint32_t>(row >> 6) * static_cast<uint32_t>(cb.patch_stride) + static_cast<uint32_t>(cb.patch_phase);
+  const uint32_t i = static_cast<uint32_t>(row) & 63u;
   const uint32_t px = p % static_cast<uint32_t>(cb.patch_w), py = p / static_cast<uint32_t>(cb.patch_w);
   return static_cast<uint32_t>(cb.row_offset) + (py * 8 + (i >> 3)) * static_cast<uint32_t>(cb.xdim) + px * 8 + (i & 7);
+}
+// index, in the host's row array of this shard, of local storage row `row`: contiguous shards hand their
+// units over in unit order, interleaved shards in storage order (somhip_shard_units lists the units)
+__device__ __forceinline__ int64_t host_row_of_row(const CbView &cb, int64_t row) {
+  return cb.patch_stride > 1 ? row : static_cast<int64_t>(unit_of_row(cb, row)) - cb.row_offset;
 }
 // lattice coordinates of local storage row `row` (som_rout.c:493-494: x = unit % xdim, y = unit / xdim)
 __device__ __forceinline__ void txty_of_row(const CbView &cb, int64_t row, int &tx, int &ty) {
@@ -42,19 +50,20 @@ __device__ __forceinline__ void txty_of_row(const CbView &cb, int64_t row, int &
     tx = static_cast<int>(u % xd); ty = static_cast<int>(u / xd);
     return;
   }
-  const uint32_t p = static_cast<uint32_t>(row >> 6), i = static_cast<uint32_t>(row) & 63u;
+  const uint32_t p = static_cast<uint32_t>(row >> 6) * static_cast<uint32_t>(cb.patch_stride) + static_cast<uint32_t>(cb.patch_phase);
+  const uint32_t i = static_cast<uint32_t>(row) & 63u;
   const uint32_t px = p % static_cast<uint32_t>(cb.patch_w), py = p / static_cast<uint32_t>(cb.patch_w);
   tx = static_cast<int>(px * 8 + (i & 7));
   ty = static_cast<int>(static_cast<uint32_t>(cb.row_offset) / xd + py * 8 + (i >> 3));
 }
 
-// local storage row of global unit index `unit` (inverse of unit_of_row)
+// local storage row of global unit index `unit` (inverse of unit_of_row; the unit must belong to the shard)
 __device__ __forceinline__ int64_t row_of_unit(const CbView &cb, uint32_t unit) {
   const uint32_t u = unit - static_cast<uint32_t>(cb.row_offset);
   if (cb.patch_w == 0) return static_cast<int64_t>(u);
   const uint32_t xd = static_cast<uint32_t>(cb.xdim);
   const uint32_t y = u / xd, x = u % xd;
-  const uint32_t p = (y >> 3) * static_cast<uint32_t>(cb.patch_w) + (x >> 3);
+  const uint32_t p = ((y >> 3) * static_cast<uint32_t>(cb.patch_w) + (x >> 3)) / static_cast<uint32_t>(cb.patch_stride);
   return static_cast<int64_t>(p) * 64 + ((y & 7) << 3) + (x & 7);
 }
 

@@ -17,7 +17,7 @@ __global__ void k_rows_to_tiles(const float *__restrict__ rows, CbView cb) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       int i = q * 4 + j;
-      v[j] = (row < cb.n && i < cb.d) ? rows[(static_cast<int64_t>(unit_of_row(cb, row)) - cb.row_offset) * cb.d + i] : 0.0f;
+      v[j] = (row < cb.n && i < cb.d) ? rows[host_row_of_row(cb, row) * cb.d + i] : 0.0f;
     }
     *tile_ptr_w(cb, g, q, lane) = make_float4(v[0], v[1], v[2], v[3]);
   }
@@ -33,7 +33,7 @@ __global__ void k_tiles_to_rows(float *__restrict__ rows, CbView cb) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       int i = q * 4 + j;
-      if (i < cb.d) rows[(static_cast<int64_t>(unit_of_row(cb, row)) - cb.row_offset) * cb.d + i] = a[j];
+      if (i < cb.d) rows[host_row_of_row(cb, row) * cb.d + i] = a[j];
     }
   }
 }

@@ -226,7 +226,12 @@ __global__ __launch_bounds__(256) void k_order_groups(const uint32_t *__restrict
 // tile's sample slices staged into LDS (one coalesced pass), then every wave applies the
 // tile's updates in order (member lanes from the entry's mask, x as broadcast reads).
 // =====================================================================================
-template <int QW, int TB, bool GAUSS, bool MASKED>
+//
+// PIPE = true is the form for small shards (few waves per SIMD, nothing to hide LDS latency behind):
+// the lane's membership bits of the whole tile are gathered first, then the entries are walked in
+// unrolled groups of 8 with the next entry's x chunks and alpha already in flight while the current
+// one is applied.  Same operations on the same values in the same order as PIPE = false.
+template <int QW, int TB, bool GAUSS, bool MASKED, bool PIPE = false>
 __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *__restrict__ rows,
                                                         const uint8_t *__restrict__ mask,
                                                         int64_t n_rows, int64_t data_first,
@@ -237,19 +242,30 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
                                                         const MemberEntry *__restrict__ ent,
                                                         const uint32_t *__restrict__ order) {
   constexpr int BQ = 4 * QW;                          // chunks per workgroup
-  __shared__ float4 xs[TB][BQ];
+  static_assert(TB % 8 == 0, "PIPE walks the tile in groups of 8 entries");
+  __shared__ float4 xs[TB + (PIPE ? 1 : 0)][BQ];              // PIPE: one row of slack for the last prefetch
   __shared__ uint32_t ms[MASKED ? TB : 1][MASKED ? BQ : 1];   // 4 mask bits per chunk
-  __shared__ float s_ga[GAUSS ? TB : 1][GAUSS ? WAVE : 1];    // gaussian: per-lane alpha
+  __shared__ float s_ga[GAUSS ? TB + 1 : 1][GAUSS ? WAVE : 1];    // gaussian: per-lane alpha
   __shared__ unsigned long long s_mask[TB];
   __shared__ long long s_xoff[TB];
-  __shared__ float s_alpha[TB], s_thr[TB];
+  __shared__ float s_alpha[TB + 1], s_thr[TB];
   __shared__ int s_bx[TB], s_by[TB];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t g = order ? order[blockIdx.x] : blockIdx.x;     // heaviest groups first
+  // Work items = (row group, slice of 4*QW chunks), heaviest groups first (K4c).  The launch is one-dimensional
+  // and walks the item list boustrophedon in blocks of 256 (one per CU): a small shard's workgroups are all
+  // resident at once, placed round-robin, and would otherwise stack the 8 or 16 slices of the heaviest groups
+  // on the same CUs; a big launch still starts its heaviest items first.
+  const uint32_t nslices = static_cast<uint32_t>((cb.d4 + BQ - 1) / BQ);
+  const uint32_t total = static_cast<uint32_t>(cb.ngroups) * nslices;
+  const uint32_t blk = blockIdx.x / 256u, pos = blockIdx.x % 256u;
+  const uint32_t bsize = total - blk * 256u < 256u ? total - blk * 256u : 256u;
+  const uint32_t item = blk * 256u + ((blk & 1u) ? bsize - 1u - pos : pos);
+  const uint32_t rank = item / nslices;
+  const int64_t g = order ? order[rank] : rank;
   const uint32_t n_ent = cnt[g];
   if (n_ent == 0) return;                             // nothing in this run touches the group
-  const int qblk = blockIdx.y * BQ;
+  const int qblk = static_cast<int>(item % nslices) * BQ;
   const int q0 = qblk + wave * QW;
   const bool vec = (cb.d & 3) == 0;
   const MemberEntry *list = ent + g * count;
@@ -271,6 +287,8 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
       s_alpha[tid] = s.alpha;
       s_xoff[tid] = ((data_first + e.sample) % n_rows) * cb.d;
       if (GAUSS) { const int2 w = bxy[e.sample]; s_bx[tid] = w.x; s_by[tid] = w.y; s_thr[tid] = s.thresh; }
+    } else if (PIPE && tid < TB) {
+      s_mask[tid] = 0ull;                             // PIPE gathers the bits of all TB slots
     }
     __syncthreads();
     // ---- sample slices -> LDS (+ gaussian: per-lane alpha, once per workgroup)
@@ -296,24 +314,49 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
     }
     __syncthreads();
     // ---- the tile's updates, in iteration order
-    if (q0 < cb.d4) {
-      for (int i = 0; i < tb; i++) {
-        if ((s_mask[i] >> lane) & 1ull) {
-          const float a = GAUSS ? s_ga[i][lane] : s_alpha[i];
+    auto apply = [&](int i, const float4 *x, float a) {
 #pragma unroll
-          for (int j = 0; j < QW; j++) {
-            const float4 n = adapt4(c[j], xs[i][wave * QW + j], a);
-            if (MASKED) {
-              const uint32_t mm = ms[i][wave * QW + j];
-              if (!(mm & 1u)) c[j].x = n.x;
-              if (!(mm & 2u)) c[j].y = n.y;
-              if (!(mm & 4u)) c[j].z = n.z;
-              if (!(mm & 8u)) c[j].w = n.w;
-            } else {
-              c[j] = n;      // padding dims: x pad = 0, c pad = 0 -> stays 0
-            }
-          }
+      for (int j = 0; j < QW; j++) {
+        const float4 n = adapt4(c[j], x[j], a);
+        if (MASKED) {
+          const uint32_t mm = ms[i][wave * QW + j];
+          if (!(mm & 1u)) c[j].x = n.x;
+          if (!(mm & 2u)) c[j].y = n.y;
+          if (!(mm & 4u)) c[j].z = n.z;
+          if (!(mm & 8u)) c[j].w = n.w;
+        } else {
+          c[j] = n;      // padding dims: x pad = 0, c pad = 0 -> stays 0
         }
+      }
+    };
+    if (PIPE) {
+      if (q0 < cb.d4) {
+        const uint32_t *m32 = reinterpret_cast<const uint32_t *>(s_mask) + (lane >> 5);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int i = 0; i < TB; i++) bits |= ((m32[2 * i] >> (lane & 31)) & 1u) << i;
+        float4 xa[QW], xb[QW];
+        float aa, ab;
+        auto fetch = [&](int i, float4 *x, float &a) {
+#pragma unroll
+          for (int j = 0; j < QW; j++) x[j] = xs[i][wave * QW + j];
+          a = GAUSS ? s_ga[i][lane] : s_alpha[i];
+        };
+        fetch(0, xa, aa);
+        for (int i0 = 0; i0 < tb; i0 += 8) {
+#pragma unroll
+          for (int u = 0; u < 8; u += 2) {
+            fetch(i0 + u + 1, xb, ab);
+            if (bits & (1u << u)) apply(i0 + u, xa, aa);
+            fetch(i0 + u + 2, xa, aa);
+            if (bits & (2u << u)) apply(i0 + u + 1, xb, ab);
+          }
+          bits >>= 8;
+        }
+      }
+    } else if (q0 < cb.d4) {
+      for (int i = 0; i < tb; i++) {
+        if ((s_mask[i] >> lane) & 1ull) apply(i, &xs[i][wave * QW], GAUSS ? s_ga[i][lane] : s_alpha[i]);
       }
     }
     __syncthreads();

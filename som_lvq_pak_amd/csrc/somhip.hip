@@ -330,10 +330,9 @@ static int upload_rows(somhip_codebook *cb, const float *rows) {
   return 0;
 }
 
-extern "C" int somhip_codebook_create(somhip_engine *e, const float *rows, const int32_t *labels,
-                                      int64_t n_rows, int dim, int topol, int neigh, int xdim,
-                                      int ydim, int64_t row_offset, int64_t n_global,
-                                      somhip_codebook **out) {
+static int codebook_create(somhip_engine *e, const float *rows, const int32_t *labels, int64_t n_rows, int dim,
+                           int topol, int neigh, int xdim, int ydim, int64_t row_offset, int64_t n_global,
+                           int patch_stride, int patch_phase, somhip_codebook **out) {
   if (!e || !rows || !out) return fail("somhip_codebook_create: null argument");
   if (n_rows <= 0 || dim <= 0) return fail("somhip_codebook_create: empty codebook (%lld x %d)", (long long)n_rows, dim);
   if (n_global < row_offset + n_rows) return fail("somhip_codebook_create: shard [%lld,%lld) outside %lld rows",
@@ -353,7 +352,13 @@ extern "C" int somhip_codebook_create(somhip_engine *e, const float *rows, const
   cb->v.topol = topol;
   cb->v.neigh = neigh;
   cb->v.patch_w = 0;
-  if (topol >= SOMHIP_TOPOL_HEXA && xdim % 8 == 0 && ydim % 8 == 0 && row_offset % (8 * (int64_t)xdim) == 0 &&
+  cb->v.patch_stride = 1;
+  cb->v.patch_phase = 0;
+  if (patch_stride > 1) {                         // interleaved shard: patch order is part of its definition
+    cb->v.patch_w = xdim / 8;
+    cb->v.patch_stride = patch_stride;
+    cb->v.patch_phase = patch_phase;
+  } else if (topol >= SOMHIP_TOPOL_HEXA && xdim % 8 == 0 && ydim % 8 == 0 && row_offset % (8 * (int64_t)xdim) == 0 &&
       n_rows % (8 * (int64_t)xdim) == 0 && !getenv("SOMHIP_LINEAR_ROWS"))
     cb->v.patch_w = xdim / 8;                     // 8x8-unit row groups (kernels.hpp CbView)
   cb->ydim = ydim;
@@ -368,6 +373,47 @@ extern "C" int somhip_codebook_create(somhip_engine *e, const float *rows, const
   }
   *out = cb;
   return 0;
+}
+
+extern "C" int somhip_codebook_create(somhip_engine *e, const float *rows, const int32_t *labels,
+                                      int64_t n_rows, int dim, int topol, int neigh, int xdim,
+                                      int ydim, int64_t row_offset, int64_t n_global,
+                                      somhip_codebook **out) {
+  return codebook_create(e, rows, labels, n_rows, dim, topol, neigh, xdim, ydim, row_offset, n_global, 1, 0, out);
+}
+
+// Interleaved shards of a map: the map is cut into 8x8-unit patches, numbered row-major; shard s of S owns
+// patches s, s+S, s+2S, ...  -- every shard sees every region of the map, so the neighbourhood updates of a
+// batch are spread evenly over the ranks whatever the radius and wherever the winners fall (contiguous row
+// blocks are not: the middle of the map is inside more neighbourhoods than its edges).
+static int shard_patch_count(int xdim, int ydim, int shard_index, int shard_count, int64_t *count) {
+  if (xdim <= 0 || ydim <= 0 || xdim % 8 || ydim % 8) return fail("interleaved shards need map sides that are multiples of 8 (%dx%d)", xdim, ydim);
+  if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail("shard %d of %d", shard_index, shard_count);
+  const int64_t patches = (int64_t)(xdim / 8) * (ydim / 8);
+  *count = patches > shard_index ? (patches - shard_index + shard_count - 1) / shard_count : 0;
+  return 0;
+}
+extern "C" int somhip_shard_units(int xdim, int ydim, int shard_index, int shard_count, int64_t *units,
+                                  int64_t *n_units) {
+  int64_t np = 0;
+  CHK(shard_patch_count(xdim, ydim, shard_index, shard_count, &np));
+  if (n_units) *n_units = np * 64;
+  if (!units) return 0;
+  CbView v{};
+  v.xdim = xdim; v.patch_w = xdim / 8; v.patch_stride = shard_count; v.patch_phase = shard_index;
+  for (int64_t r = 0; r < np * 64; r++) units[r] = shard_count == 1 ? r : (int64_t)unit_of_row(v, r);   // one shard = the whole map, unit order
+  return 0;
+}
+extern "C" int somhip_codebook_create_interleaved(somhip_engine *e, const float *rows, int64_t n_rows, int dim,
+                                                  int topol, int neigh, int xdim, int ydim, int shard_index,
+                                                  int shard_count, somhip_codebook **out) {
+  if (topol < SOMHIP_TOPOL_HEXA) return fail("somhip_codebook_create_interleaved: maps only");
+  int64_t np = 0;
+  CHK(shard_patch_count(xdim, ydim, shard_index, shard_count, &np));
+  if (n_rows != np * 64) return fail("somhip_codebook_create_interleaved: shard %d of %d of a %dx%d map has %lld units, not %lld",
+                                     shard_index, shard_count, xdim, ydim, (long long)(np * 64), (long long)n_rows);
+  return codebook_create(e, rows, nullptr, n_rows, dim, topol, neigh, xdim, ydim, 0, (int64_t)xdim * ydim,
+                         shard_count > 1 ? shard_count : 1, shard_count > 1 ? shard_index : 0, out);
 }
 extern "C" int somhip_codebook_upload(somhip_codebook *cb, const float *rows) {
   HIPCHK(hipSetDevice(cb->e->device));

@@ -110,11 +110,23 @@ class Engine:
             pass
 
 
+def shard_units(xdim, ydim, shard_index, shard_count, lib=None):
+    """Global unit indices of the rows of interleaved shard `shard_index` of `shard_count` (somhip_shard_units)."""
+    lib = lib or _lib.load()
+    n = C.c_int64()
+    check(lib.somhip_shard_units(xdim, ydim, shard_index, shard_count, None, C.byref(n)))
+    units = np.empty(n.value, dtype=np.int64)
+    check(lib.somhip_shard_units(xdim, ydim, shard_index, shard_count, _p(units, _lib.c_i64_p), C.byref(n)))
+    return units
+
+
 class Codebook:
     """Device mirror of the `codes` list (reference lvq_pak.h:89-113)."""
 
     def __init__(self, engine, rows, topol=TOPOL_LVQ, neigh=0, xdim=0, ydim=0, labels=None,
-                 row_offset=0, n_global=None):
+                 row_offset=0, n_global=None, interleave=None):
+        """interleave=(shard_index, shard_count): `rows` are the units shard_units(...) lists, in that order
+        (somhip_codebook_create_interleaved); otherwise the contiguous rows [row_offset, row_offset + n)."""
         self.e = engine
         rows = _arr(rows, np.float32)
         self.n, self.dim = rows.shape
@@ -124,9 +136,16 @@ class Codebook:
         self.row_offset = row_offset
         self.n_global = self.n if n_global is None else n_global
         h = C.c_void_p()
-        check(engine.lib.somhip_codebook_create(engine.h, _p(rows, _lib.c_float_p), _p(labels, _lib.c_i32_p),
-                                                self.n, self.dim, topol, neigh, xdim, ydim, row_offset,
-                                                self.n_global, C.byref(h)))
+        self.interleave = interleave
+        if interleave is not None:
+            self.n_global = xdim * ydim
+            check(engine.lib.somhip_codebook_create_interleaved(engine.h, _p(rows, _lib.c_float_p), self.n, self.dim,
+                                                                topol, neigh, xdim, ydim, interleave[0],
+                                                                interleave[1], C.byref(h)))
+        else:
+            check(engine.lib.somhip_codebook_create(engine.h, _p(rows, _lib.c_float_p), _p(labels, _lib.c_i32_p),
+                                                    self.n, self.dim, topol, neigh, xdim, ydim, row_offset,
+                                                    self.n_global, C.byref(h)))
         self.h = h
         engine._adopt(self)
 
