@@ -268,15 +268,17 @@ __device__ __forceinline__ void split8(const float4 a, const float4 b, uint4 &hi
   lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
-// squared norms (fp32, as k_row_norms) + bf16 hi/lo tiles of the codebook, one pass
+// squared norms (fp32) + bf16 hi/lo tiles of the codebook, one pass.  One workgroup per row group; its
+// blockDim/64 waves (up to 16) take the k-blocks round-robin and their partial norms are added in wave order
+// (the bound tau is built from holds for any summation order, and this one is fixed).
 __global__ void k_prep_codes_bf16(CbView cb, int d8, float *__restrict__ cn,
                                   unsigned int *__restrict__ cn_max_bits, uint4 *__restrict__ chi,
                                   uint4 *__restrict__ clo) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave;
-  if (g >= cb.ngroups) return;
+  __shared__ float s_part[16][WAVE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int64_t g = blockIdx.x;
   float acc = 0.0f;
-  for (int kb = 0; kb < d8; kb++) {
+  for (int kb = wave; kb < d8; kb += nw) {
     const float4 a = *tile_ptr(cb, g, 2 * kb, lane);
     const float4 b = (2 * kb + 1 < cb.d4) ? *tile_ptr(cb, g, 2 * kb + 1, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
     acc += a.x * a.x; acc += a.y * a.y; acc += a.z * a.z; acc += a.w * a.w;
@@ -286,6 +288,11 @@ __global__ void k_prep_codes_bf16(CbView cb, int d8, float *__restrict__ cn,
     chi[(g * d8 + kb) * WAVE + lane] = hi;
     clo[(g * d8 + kb) * WAVE + lane] = lo;
   }
+  s_part[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0) return;
+  acc = s_part[0][lane];
+  for (int w = 1; w < nw; w++) acc += s_part[w][lane];
   const int64_t row = g * WAVE + lane;
   cn[row] = row < cb.n ? acc : 3.0e38f;
   float m = row < cb.n ? acc : 0.0f;
@@ -331,23 +338,34 @@ __global__ __launch_bounds__(256) void k_max_norm(CbView cb, const float *__rest
   if ((threadIdx.x & 63) == 0) atomicMax(cn_max_bits, __float_as_uint(m));
 }
 
-// a run of samples -> bf16 hi/lo sample tiles xt[sb][kb][32][8]
+// a run of samples -> bf16 hi/lo sample tiles xt[sb][kb][32][8].  grid = (32-sample tiles, slices of the k-blocks)
 __global__ void k_pack_samples_bf16(const float *__restrict__ rows, int64_t n_rows, int d, int d8,
                                     int64_t first, int64_t count, uint4 *__restrict__ xhi,
                                     uint4 *__restrict__ xlo, unsigned int *__restrict__ zero_word) {
   const int64_t sb = blockIdx.x;
-  if (zero_word && sb == 0 && threadIdx.x == 0) *zero_word = 0u;   // max ||c||^2 accumulator of the next kernel
-  for (int e = threadIdx.x; e < d8 * 32; e += blockDim.x) {
-    const int kb = e / 32, sidx = e % 32;
+  if (zero_word && sb == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_word = 0u;   // max ||c||^2 accumulator of the next kernel
+  const int per = (d8 + gridDim.y - 1) / gridDim.y;
+  const int kb_lo = blockIdx.y * per, kb_hi = kb_lo + per < d8 ? kb_lo + per : d8;
+  const bool vec = (d & 7) == 0 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0;   // two aligned float4 per k-block
+  for (int e = threadIdx.x; e < (kb_hi - kb_lo) * 32; e += blockDim.x) {
+    const int kb = kb_lo + e / 32, sidx = e % 32;
     const int64_t smp = sb * 32 + sidx;
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (smp < count) {
       const float *x = rows + ((first + smp) % n_rows) * d;
+      if (vec) {
+        a = reinterpret_cast<const float4 *>(x)[2 * kb];
+        b = reinterpret_cast<const float4 *>(x)[2 * kb + 1];
+      } else {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 8; j++) if (kb * 8 + j < d) v[j] = x[kb * 8 + j];
+        for (int j = 0; j < 8; j++) if (kb * 8 + j < d) v[j] = x[kb * 8 + j];
+        a = make_float4(v[0], v[1], v[2], v[3]);
+        b = make_float4(v[4], v[5], v[6], v[7]);
+      }
     }
     uint4 hi, lo;
-    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+    split8(a, b, hi, lo);
     xhi[(sb * d8 + kb) * 32 + sidx] = hi;
     xlo[(sb * d8 + kb) * 32 + sidx] = lo;
   }

@@ -337,22 +337,40 @@ __global__ __launch_bounds__(256) void k_rerank_select(CbView cb, int64_t count,
   const bool live = b < count;
   const float thr = live ? ordered_to_float(gmin[b]) + tau[b] : -3.4e38f;
   unsigned ngr = 0, nrow = 0;
-  for (int64_t g0 = g_lo; g0 < g_hi; g0 += 8) {
-    const int64_t g = g0 + gy;
-    unsigned long long mask = 0;
-    if (live && g < g_hi && wmin[g * bpad + b] <= thr) {
-      mask = wmask[g * bpad + b];
-      // drop padding rows of the last group: bit 32h+16i+r is row 32i + (r&3) + 8(r>>2) + 4h
-      if ((g + 1) * WAVE > cb.n) {
-        unsigned long long keep = 0;
-        for (int t = 0; t < 64; t++) {
-          const int h = t >> 5, i = (t >> 4) & 1, r = t & 15;
-          if (g * WAVE + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h < cb.n) keep |= 1ull << t;
-        }
-        mask &= keep;
-      }
+  uint2 *seg = pairs + static_cast<size_t>(blockIdx.x) * cap_col;
+  // blocks of 64 groups (8 per thread): all the loads of a block are issued together and the wave reserves
+  // its room in the segment once per block -- the atomic's round trip, taken once per 8 groups, was most
+  // of this kernel's time
+  for (int64_t g0 = g_lo; g0 < g_hi; g0 += 64) {
+    float wv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int64_t g = g0 + 8 * k + gy;
+      wv[k] = (live && g < g_hi) ? wmin[g * bpad + b] : 3.4e38f;
     }
-    const unsigned n = __popcll(mask);
+    unsigned long long mk[8];
+    unsigned n = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int64_t g = g0 + 8 * k + gy;
+      unsigned long long mask = 0;
+      if (wv[k] <= thr && live && g < g_hi) {
+        mask = wmask[g * bpad + b];
+        // drop padding rows of the last group: bit 32h+16i+r is row 32i + (r&3) + 8(r>>2) + 4h
+        if ((g + 1) * WAVE > cb.n) {
+          unsigned long long keep = 0;
+          for (int t = 0; t < 64; t++) {
+            const int h = t >> 5, i = (t >> 4) & 1, r = t & 15;
+            if (g * WAVE + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h < cb.n) keep |= 1ull << t;
+          }
+          mask &= keep;
+        }
+      }
+      mk[k] = mask;
+      const unsigned c = __popcll(mask);
+      n += c;
+      ngr += c != 0;
+    }
     if (__ballot(n != 0) == 0) continue;                 // wave-uniform
     // wave-aggregated reservation in the pair list
     unsigned pre = n;
@@ -367,20 +385,22 @@ __global__ __launch_bounds__(256) void k_rerank_select(CbView cb, int64_t count,
       base = atomicAdd(col_count + blockIdx.x, wave_total);
       if (base + wave_total > cap_col) atomicMax(pair_count, cap + 1);
     }
-    base = __shfl(base, 0, WAVE) + pre - n;
+    unsigned at = __shfl(base, 0, WAVE) + pre - n;
+    nrow += n;
     if (n) {
-      ngr++; nrow += n;
-      unsigned at = base;
-      unsigned long long mm = mask;
-      uint2 *seg = pairs + static_cast<size_t>(blockIdx.x) * cap_col;
-      while (mm) {
-        const int t = __builtin_ctzll(mm);
-        mm &= mm - 1;
-        const int h = t >> 5, i = (t >> 4) & 1, r = t & 15;
-        if (at < cap_col)
-          seg[at] = make_uint2(static_cast<uint32_t>(b),
-                               static_cast<uint32_t>(g * WAVE + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h));
-        at++;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int64_t g = g0 + 8 * k + gy;
+        unsigned long long mm = mk[k];
+        while (mm) {
+          const int t = __builtin_ctzll(mm);
+          mm &= mm - 1;
+          const int h = t >> 5, i = (t >> 4) & 1, r = t & 15;
+          if (at < cap_col)
+            seg[at] = make_uint2(static_cast<uint32_t>(b),
+                                 static_cast<uint32_t>(g * WAVE + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h));
+          at++;
+        }
       }
     }
   }
@@ -417,10 +437,16 @@ __global__ __launch_bounds__(256) void k_rerank_pairs(CbView cb, const float *__
                                                       uint64_t *__restrict__ keys,
                                                       unsigned long long *__restrict__ stats) {
   // A fixed, small grid (workgroup launches cost ~50 ns each: a grid sized for the worst case was
-  // the whole cost of this kernel).  Every workgroup builds the same table of 256-entry chunks per
+  // the whole cost of this kernel).  Every workgroup builds the same table of 64-pair chunks per
   // column (prefix sums of the segment fills) and takes chunks round-robin.
+  //
+  // Four lanes share a pair.  The sum over the dims has to be one sequential chain, but the subtract and
+  // the square are element-wise: lane j of the quad loads chunks q = j (mod 4) of the row (16 bytes out of
+  // every KiB -- a quarter of the scattered reads per lane, four times the waves) and of the sample,
+  // squares its differences, and every lane of the quad then adds the products in dim order, fetching
+  // each through a quad-broadcast DPP operand.  Same roundings in the same order as sq_acc.
   __shared__ uint32_t s_pref[PAIR_MAX_COLS + 1];
-  __shared__ uint32_t s_scan[256];
+  __shared__ uint32_t s_scan[4];
   const int tid = threadIdx.x;
   if (blockIdx.x == 0 && *pair_count <= cap) {            // the columns' statistics, once
     for (int c = tid; c < ncols; c += 256) {
@@ -432,61 +458,74 @@ __global__ __launch_bounds__(256) void k_rerank_pairs(CbView cb, const float *__
   if (*pair_count > cap) return;                         // a segment overflowed: K2r does the whole run
   const int per = (ncols + 255) / 256;
   uint32_t mine = 0;
-  for (int c = tid * per; c < (tid + 1) * per && c < ncols; c++) mine += (col_count[c] + 255u) >> 8;
-  s_scan[tid] = mine;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
-    __syncthreads();
-    s_scan[tid] += v;
-    __syncthreads();
+  for (int c = tid * per; c < (tid + 1) * per && c < ncols; c++) mine += (col_count[c] + 63u) >> 6;
+  uint32_t inc = mine;                                   // inclusive scan: in the wave by shuffles, then the 4 wave totals
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    const uint32_t v = __shfl_up(inc, off, WAVE);
+    if ((tid & 63) >= off) inc += v;
   }
+  if ((tid & 63) == 63) s_scan[tid >> 6] = inc;
+  __syncthreads();
+  for (int w = 0; w < (tid >> 6); w++) inc += s_scan[w];
   {
-    uint32_t run = s_scan[tid] - mine;                   // exclusive prefix of this thread's columns
-    for (int c = tid * per; c < (tid + 1) * per && c < ncols; c++) { s_pref[c] = run; run += (col_count[c] + 255u) >> 8; }
-    if (tid == 255) s_pref[ncols] = s_scan[255];
+    uint32_t run = inc - mine;                           // exclusive prefix of this thread's columns
+    for (int c = tid * per; c < (tid + 1) * per && c < ncols; c++) { s_pref[c] = run; run += (col_count[c] + 63u) >> 6; }
+    if (tid == 255) s_pref[ncols] = inc;
   }
   __syncthreads();
   const uint32_t total = s_pref[ncols];
   const bool vec = (cb.d & 3) == 0;
+  const int j = tid & 3;
   for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
     int lo = 0, hi = ncols;                              // column with s_pref[col] <= id < s_pref[col + 1]
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[mid] <= id) lo = mid; else hi = mid; }
-    const uint32_t slot = (id - s_pref[lo]) * 256u + tid;
-    if (slot >= col_count[lo]) continue;
+    const uint32_t slot = (id - s_pref[lo]) * 64u + (tid >> 2);
+    if (slot >= col_count[lo]) continue;                 // quad-uniform
     const uint2 pr = pairs[static_cast<size_t>(lo) * cap_col + slot];
     const int64_t row = pr.y;
     const float4 *crow = reinterpret_cast<const float4 *>(cb.tiles) + ((row >> 6) * cb.d4) * WAVE + (row & 63);
     const float *x = rows + ((first + pr.x) % n_rows) * cb.d;
     float acc = 0.0f;
-    // 8 chunks of the row and of the sample in flight per lane (independent loads first)
-    constexpr int UP = 8;
-    int q = 0;
-    for (; q + UP <= cb.d4; q += UP) {
+    constexpr int UP = 8;                                // chunks per lane and round: 32 chunks of the pair in flight
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q0 = 0; q0 < cb.d4; q0 += 4 * UP) {
       float4 cc[UP], xx[UP];
+      if (vec && q0 + 4 * UP <= cb.d4) {                 // whole round in range: 16 unconditional loads in flight
+        const float4 *cq = crow + static_cast<int64_t>(q0 + j) * WAVE;
+        const float4 *xq = reinterpret_cast<const float4 *>(x) + q0 + j;
 #pragma unroll
-      for (int u = 0; u < UP; u++) {
-        cc[u] = crow[static_cast<int64_t>(q + u) * WAVE];
-        xx[u] = vec ? reinterpret_cast<const float4 *>(x)[q + u] : load_x4<false>(x, q + u, cb.d);
+        for (int u = 0; u < UP; u++) { cc[u] = cq[static_cast<int64_t>(4 * u) * WAVE]; xx[u] = xq[4 * u]; }
+      } else {
+#pragma unroll
+        for (int u = 0; u < UP; u++) {
+          const int q = q0 + 4 * u + j;
+          const bool in = q < cb.d4;                     // past the end: (0 - 0)^2 = +0, exact to add
+          cc[u] = in ? crow[static_cast<int64_t>(q) * WAVE] : zero4;
+          xx[u] = !in ? zero4 : vec ? reinterpret_cast<const float4 *>(x)[q] : load_x4<false>(x, q, cb.d);
+        }
       }
 #pragma unroll
       for (int u = 0; u < UP; u++) {
-        acc = sq_acc(acc, cc[u].x, xx[u].x);
-        acc = sq_acc(acc, cc[u].y, xx[u].y);
-        acc = sq_acc(acc, cc[u].z, xx[u].z);
-        acc = sq_acc(acc, cc[u].w, xx[u].w);
+        float t;
+        t = cc[u].x - xx[u].x; cc[u].x = t * t;
+        t = cc[u].y - xx[u].y; cc[u].y = t * t;
+        t = cc[u].z - xx[u].z; cc[u].z = t * t;
+        t = cc[u].w - xx[u].w; cc[u].w = t * t;
       }
+#define QB(V, CTRL) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(V), CTRL, 0xF, 0xF, false))
+#define QADD(U, CTRL) acc = acc + QB(cc[U].x, CTRL); acc = acc + QB(cc[U].y, CTRL); acc = acc + QB(cc[U].z, CTRL); acc = acc + QB(cc[U].w, CTRL);
+#pragma unroll
+      for (int u = 0; u < UP; u++) {                     // chunks q0 + 4u .. q0 + 4u + 3, held by quad lanes 0..3
+        QADD(u, 0x00) QADD(u, 0x55) QADD(u, 0xAA) QADD(u, 0xFF)
+      }
+#undef QADD
+#undef QB
     }
-    for (; q < cb.d4; q++) {
-      const float4 c = crow[static_cast<int64_t>(q) * WAVE];
-      const float4 xv = vec ? reinterpret_cast<const float4 *>(x)[q] : load_x4<false>(x, q, cb.d);
-      acc = sq_acc(acc, c.x, xv.x);
-      acc = sq_acc(acc, c.y, xv.y);
-      acc = sq_acc(acc, c.z, xv.z);
-      acc = sq_acc(acc, c.w, xv.w);
+    if (j == 0) {
+      const uint64_t k = make_key(acc, unit_of_row(cb, row));
+      atomicMin(reinterpret_cast<unsigned long long *>(keys + pr.x), static_cast<unsigned long long>(k));
     }
-    const uint64_t k = make_key(acc, unit_of_row(cb, row));
-    atomicMin(reinterpret_cast<unsigned long long *>(keys + pr.x), static_cast<unsigned long long>(k));
   }
 }
 

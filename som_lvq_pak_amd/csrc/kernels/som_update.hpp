@@ -42,15 +42,18 @@ __global__ void k_decode_winners(const uint64_t *__restrict__ keys, const StepSc
 // =====================================================================================
 struct MemberEntry { uint32_t sample; float alpha; unsigned long long mask; };   // alpha: the iteration's rate
 
-template <bool GAUSS>
-__global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
+template <bool GAUSS, int NT>          // NT threads: 256, or 1024 when a small shard has few row groups to spread
+__global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
                                                      const int2 *__restrict__ bxy,
                                                      const uint64_t *__restrict__ keys,
                                                      const StepScalars *__restrict__ sc,
                                                      uint32_t *__restrict__ cnt,
                                                      MemberEntry *__restrict__ ent,
                                                      unsigned long long *__restrict__ stats) {
-  __shared__ uint32_t s_wcount[4];
+  constexpr int RR = 4;                 // samples per thread and trip: their loads are issued together
+  constexpr int NW = NT / 64;
+  static_assert(RR * NW <= 64, "the (round, wave) counts are scanned by one wavefront");
+  __shared__ uint32_t s_wcount[RR * NW + 1];             // counts, then exclusive prefix (+ total) per trip
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t g = blockIdx.x;
   const uint32_t xdim = static_cast<uint32_t>(cb.xdim);
@@ -70,13 +73,12 @@ __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
   uint32_t base = 0;
   unsigned long long rows_total = 0, pairs_total = 0;
 
-  constexpr int RR = 4;                 // samples per thread and trip: their loads are issued together
-  for (int64_t b0 = 0; b0 < count; b0 += 256 * RR) {
+  for (int64_t b0 = 0; b0 < count; b0 += NT * RR) {
     unsigned long long mm[RR];
     float al[RR];
 #pragma unroll
     for (int r = 0; r < RR; r++) {
-      const int64_t b = b0 + 256 * r + tid;
+      const int64_t b = b0 + NT * r + tid;
       unsigned long long m = 0;
       float alpha_b = 0.f;
       if (b < count) {
@@ -152,27 +154,39 @@ __global__ __launch_bounds__(256) void k_som_members(CbView cb, int64_t count,
       mm[r] = m;
       al[r] = alpha_b;
     }
+    // ordered compaction of the trip: ballots -> (round, wave) counts -> one wavefront scans them
+    unsigned long long bal[RR];
 #pragma unroll
     for (int r = 0; r < RR; r++) {
-      if (b0 + 256 * r >= count) break;                 // uniform
-      const int64_t b = b0 + 256 * r + tid;
+      bal[r] = __ballot(mm[r] != 0);
+      if (lane == 0) s_wcount[r * NW + wave] = __popcll(bal[r]);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const uint32_t c = lane < RR * NW ? s_wcount[lane] : 0u;
+      uint32_t inc = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, WAVE);
+        if (lane >= off) inc += o;
+      }
+      if (lane < RR * NW) s_wcount[lane] = inc - c;
+      if (lane == RR * NW - 1) s_wcount[RR * NW] = inc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RR; r++) {
       const unsigned long long m = mm[r];
-      const bool on = m != 0;
-      const unsigned long long bal = __ballot(on);
-      if (lane == 0) s_wcount[wave] = __popcll(bal);
-      __syncthreads();
-      uint32_t off = base;
-      for (int w2 = 0; w2 < wave; w2++) off += s_wcount[w2];
-      if (on) {
+      if (m != 0) {
         MemberEntry e;
-        e.sample = static_cast<uint32_t>(b); e.alpha = al[r]; e.mask = m;
-        out[off + __popcll(bal & ((1ull << lane) - 1))] = e;
+        e.sample = static_cast<uint32_t>(b0 + NT * r + tid); e.alpha = al[r]; e.mask = m;
+        out[base + s_wcount[r * NW + wave] + __popcll(bal[r] & ((1ull << lane) - 1))] = e;
         rows_total += __popcll(m);
         pairs_total += 1;
       }
-      base += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
-      __syncthreads();
     }
+    base += s_wcount[RR * NW];
+    __syncthreads();
   }
   if (tid == 0) cnt[g] = base;
   // instrumentation: (row, iteration) updates and (row group, iteration) pairs of this run
