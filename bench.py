@@ -164,7 +164,7 @@ def main():
 
     # ---- timed region: one complete training run of K*B vectors ----
     if world > 1:      # N > 1: steps are short; event only the two kernels the roofline lines need
-        eng.timing_select({"k_som_update_run", "k_dist_mfma_bf16", "k_dist_mfma", "k_scan_exact"})
+        eng.timing_select({"k_som_update_run", "k_som_update_bubble_s", "k_dist_mfma_bf16", "k_dist_mfma", "k_scan_exact"})
     eng.timing(True)
     eng.timing_reset()
     stats_before = eng.scan_stats()
@@ -243,7 +243,7 @@ def main():
                 alg = 3.0 * n_local * d * B                     # direct form: sub, mul, add
                 note = ("direct-form fp32 scan on the vector ALU, 3*N*d flop per vector; no FMA allowed, so its "
                         "ceiling is half the fp32 peak")
-            elif kname == "k_som_update_run":
+            elif kname in ("k_som_update_run", "k_som_update_bubble_s"):
                 alg = 3.0 * d * rows_upd / max(kl, 1)           # c += a*(x-c): sub, mul, add per element
                 note = ("in-order neighbourhood update on the vector ALU: 3*d flop per (row, iteration) update, "
                         "%.0f row updates per launch counted by the kernel; no FMA allowed (ceiling = half the "

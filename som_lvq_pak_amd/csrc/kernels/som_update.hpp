@@ -380,4 +380,138 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
     if (q0 + j < cb.d4) *tile_ptr_w(cb, g, q0 + j, lane) = c[j];
 }
 
+// =====================================================================================
+// K4s: the same in-order update for the common case (bubble neighbourhood, no masks, dim % 4 == 0), with
+// everything that is uniform over a wavefront kept out of the vector unit and out of LDS.
+//
+// In K4 every entry costs each wave a broadcast ds_read_b128 per chunk (the LDS pipe, shared by the CU's four
+// SIMDs, saturates before the vector ALUs do), a staging pass and two barriers per tile, and ~8 vector
+// instructions to turn the entry's mask into an exec mask.  Here a wave is on its own: the member entry
+// {sample, alpha, mask} and the sample's 4*QW dims arrive by *scalar* loads (constant address space: the
+// list and the data are not written by this kernel), the mask becomes the exec mask directly
+// (inverse ballot), alpha and x are SGPR operands of the sub/mul/add, and the next entry's loads are in
+// flight while the current one is applied.  No LDS, no barriers; arithmetic and order exactly K4's.
+// =====================================================================================
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+// The scalar loads and the waits are inline assembly: the compiler would otherwise sink each load to its
+// first use (inside the next entry's exec-masked block), i.e. issue it and wait for it at once.  Scalar
+// loads return out of order, so a wait is always lgkmcnt(0); a buffer is only read after it has been passed
+// through k4s_wait (in/out operand), which is what orders its uses behind the wait.
+template <int NF> struct K4sX;
+template <> struct K4sX<8> {
+  f32x8_t v;
+  __device__ __forceinline__ void load(const float *p) { asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(v) : "s"(p)); }
+  __device__ __forceinline__ void wait(u32x4_t &e) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+s"(e)); }
+  __device__ __forceinline__ float4 chunk(int j) const { return make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]); }
+};
+template <> struct K4sX<16> {
+  f32x16_t v;
+  __device__ __forceinline__ void load(const float *p) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p)); }
+  __device__ __forceinline__ void wait(u32x4_t &e) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+s"(e)); }
+  __device__ __forceinline__ float4 chunk(int j) const { return make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]); }
+};
+template <> struct K4sX<32> {
+  f32x16_t v, w;
+  __device__ __forceinline__ void load(const float *p) {
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(v), "=&s"(w) : "s"(p));
+  }
+  __device__ __forceinline__ void wait(u32x4_t &e) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+s"(w), "+s"(e)); }
+  __device__ __forceinline__ float4 chunk(int j) const {
+    return j < 4 ? make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3])
+                 : make_float4(w[4 * j - 16], w[4 * j - 15], w[4 * j - 14], w[4 * j - 13]);
+  }
+};
+__device__ __forceinline__ void k4s_load_entry(u32x4_t &e, const MemberEntry *p) {
+  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(e) : "s"(p));
+}
+
+template <int QW, bool PK = false>
+__global__ __launch_bounds__(256) void k_som_update_bubble_s(CbView cb, const float *__restrict__ rows,
+                                                             int64_t n_rows, int64_t data_first, int64_t count,
+                                                             const uint32_t *__restrict__ cnt,
+                                                             const MemberEntry *__restrict__ ent,
+                                                             const uint32_t *__restrict__ order) {
+  static_assert(sizeof(MemberEntry) == 16, "one s_load_dwordx4 per entry");
+  constexpr int BQ = 4 * QW;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // (row group, slice) items in the CU-balanced order of K4
+  const uint32_t nslices = static_cast<uint32_t>(cb.d4 / BQ);          // host: d4 % BQ == 0
+  const uint32_t total = static_cast<uint32_t>(cb.ngroups) * nslices;
+  const uint32_t blk = blockIdx.x / 256u, pos = blockIdx.x % 256u;
+  const uint32_t bsize = total - blk * 256u < 256u ? total - blk * 256u : 256u;
+  const uint32_t item = blk * 256u + ((blk & 1u) ? bsize - 1u - pos : pos);
+  const uint32_t rank = item / nslices;
+  const int64_t g = order ? order[rank] : rank;
+  const uint32_t n_ent = cnt[g];
+  if (n_ent == 0) return;
+  const int q0 = static_cast<int>(item % nslices) * BQ + wave * QW;
+
+  float4 c[QW];
+#pragma unroll
+  for (int j = 0; j < QW; j++) c[j] = *tile_ptr(cb, g, q0 + j, lane);
+
+  const MemberEntry *list = ent + g * count;
+  const float *xbase = rows + 4 * q0;
+  const uint32_t last = n_ent - 1u;
+  const uint32_t nr = static_cast<uint32_t>(n_rows), df = static_cast<uint32_t>(data_first);   // host: n_rows < 2^31
+  auto xrow = [&](const u32x4_t &e) -> const float * {
+    uint32_t r = df + e.x;                             // host: count <= n_rows, so one wrap at most
+    if (r >= nr) r -= nr;
+    return xbase + static_cast<int64_t>(r) * cb.d;
+  };
+  auto entry = [&](uint32_t k) -> const MemberEntry * {      // clamped: past the end the last entry is re-read, never applied
+    return list + __builtin_amdgcn_readfirstlane(static_cast<int>(k < last ? k : last));
+  };
+  auto apply = [&](const u32x4_t &e, const K4sX<4 * QW> &x) {
+    if (__builtin_amdgcn_inverse_ballot_w64((static_cast<unsigned long long>(e.w) << 32) | e.z)) {
+      const float a = __uint_as_float(e.y);
+      if (PK) {                                        // v_pk_add/mul_f32: two elements per instruction, each half rounded like the scalar op
+        const f32x2 a2 = {a, a};
+#pragma unroll
+        for (int j = 0; j < QW; j++) {
+          const float4 xv = x.chunk(j);
+          f32x2 lo = {c[j].x, c[j].y}, hi = {c[j].z, c[j].w};
+          const f32x2 tl = f32x2{xv.x, xv.y} - lo, th = f32x2{xv.z, xv.w} - hi;
+          const f32x2 sl = a2 * tl, sh = a2 * th;
+          lo = lo + sl; hi = hi + sh;
+          c[j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < QW; j++) c[j] = adapt4(c[j], x.chunk(j), a);
+      }
+    }
+  };
+  // Phase k: wait -> x_k and entry k+2 have landed; issue x_{k+1} and entry k+3; apply entry k from registers.
+  // Four entry buffers and two x buffers in pure rotation (the loop is unrolled over the four phases), so no
+  // value ever has to be copied between a load and the wait that makes it readable -- the compiler knows nothing
+  // about that window (tests/test_build.py checks the ISA for it).
+  u32x4_t e0, e1, e2, e3;
+  K4sX<4 * QW> xA, xB;
+  k4s_load_entry(e0, entry(0));
+  k4s_load_entry(e1, entry(1));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e0), "+s"(e1));
+  xA.load(xrow(e0));
+  k4s_load_entry(e2, entry(2));
+#define K4S_PHASE(XC, XN, EK, EK1, EK2, EK3) \
+  XC.wait(EK2);                              \
+  XN.load(xrow(EK1));                        \
+  k4s_load_entry(EK3, entry(k + 3u));        \
+  apply(EK, XC);                             \
+  if (++k >= n_ent) break;
+  for (uint32_t k = 0;;) {
+    K4S_PHASE(xA, xB, e0, e1, e2, e3)
+    K4S_PHASE(xB, xA, e1, e2, e3, e0)
+    K4S_PHASE(xA, xB, e2, e3, e0, e1)
+    K4S_PHASE(xB, xA, e3, e0, e1, e2)
+  }
+#undef K4S_PHASE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing of ours may still be landing in SGPRs at exit
+#pragma unroll
+  for (int j = 0; j < QW; j++) *tile_ptr_w(cb, g, q0 + j, lane) = c[j];
+}
+
 }  // namespace somhip

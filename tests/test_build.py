@@ -74,3 +74,43 @@ def test_exact_kernels_have_no_fma(built, tmp_path):
         assert not bad, (name, bad[:3])
         assert re.search(r"v_(pk_)?mul_f32", body) and re.search(r"v_(pk_)?add_f32", body)
     assert checked >= 6
+
+
+def test_scalar_update_kernel_reads_nothing_before_its_wait(built, tmp_path):
+    """k_som_update_bubble_s issues its scalar loads from inline assembly, so the compiler's own
+    s_waitcnt insertion does not cover them: the kernel relies on nothing reading a load's destination
+    SGPRs between the s_load and the next `s_waitcnt lgkmcnt(0)`.  Check exactly that on the ISA
+    (linear scan, which is conservative for the loop: every phase has its own wait), and that the
+    arithmetic stayed sub/mul/add."""
+    s = os.path.join(str(tmp_path), "k.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                           "-ffp-contract=off", "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", s,
+                           os.path.join(ROOT, "som_lvq_pak_amd", "csrc", "somhip.hip")])
+    txt = open(s).read()
+    bodies = dict(re.findall(r"^(_ZN6somhip21k_som_update_bubble_s\w+):.*?\n(.*?)s_endpgm", txt, flags=re.S | re.M))
+    assert len(bodies) >= 2
+
+    def sregs(text):
+        out = set()
+        for a, b, c in re.findall(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b", text):
+            out.update(range(int(a), int(b) + 1) if a else [int(c)])
+        return out
+
+    for name, body in bodies.items():
+        assert not re.findall(r"\bv_(?:pk_)?(?:fma|fmac|mac|mad)_f32\b.*", body), name
+        pending, loads = set(), 0
+        for line in body.splitlines():
+            ins = line.split(";")[0].strip()
+            if not ins or ins.endswith(":") or ins.startswith("."):
+                continue
+            if ins.startswith("s_waitcnt") and "lgkmcnt(0)" in ins:
+                pending.clear()
+                continue
+            m = re.match(r"s_load_dword(?:x\d+)?\s+(s\[\d+:\d+\]|s\d+)\s*,(.*)", ins)
+            if m:
+                assert not (sregs(m.group(2)) & pending), (name, ins)
+                pending |= sregs(m.group(1))
+                loads += 1
+                continue
+            assert not (sregs(ins) & pending), (name, ins, sorted(pending))
+        assert loads >= 8, name

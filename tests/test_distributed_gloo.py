@@ -23,12 +23,13 @@ def _free_port():
 
 
 class CheckerShard:
-    """winner_keys/update for one row shard, computed with the CPU oracle."""
+    """winner_keys/update for one shard, computed with the CPU oracle.  `units`: the global unit index of
+    every local row (a contiguous block, or the interleaved 8x8 patches of somhip_shard_units)."""
 
-    def __init__(self, orc, rows, r0, n_global, xdim, topol, neigh, data, length, alpha, radius):
+    def __init__(self, orc, rows, units, n_global, xdim, topol, neigh, data, length, alpha, radius):
         import torch
         self.torch = torch
-        self.orc, self.rows, self.r0 = orc, rows.copy(), r0
+        self.orc, self.rows, self.units = orc, rows.copy(), np.asarray(units, dtype=np.int64)
         self.xdim, self.topol, self.neigh = xdim, topol, neigh
         self.data, self.length, self.alpha, self.radius = data, length, alpha, radius
 
@@ -36,7 +37,7 @@ class CheckerShard:
         from som_lvq_pak_amd.sharded import pack_keys
         idx = [(first + j) % self.data.shape[0] for j in range(count)]
         wi, wd, _ = self.orc.winners(self.rows, self.data[idx])
-        keys = pack_keys(wd[:, 0], wi[:, 0] + self.r0)
+        keys = pack_keys(wd[:, 0], self.units[wi[:, 0]])
         return self.torch.from_numpy(keys.view(np.int64).copy())
 
     def update(self, it0, count, first, keys):
@@ -49,7 +50,7 @@ class CheckerShard:
             talp = self.orc.alpha(1, le, self.length, self.alpha)
             bx, by = int(widx[j] % self.xdim), int(widx[j] // self.xdim)
             for k in range(self.rows.shape[0]):
-                g = k + self.r0
+                g = int(self.units[k])
                 dd = self.orc.mapdist(self.topol, bx, by, g % self.xdim, g // self.xdim)
                 if self.neigh == 2:
                     self.rows[k] = self.orc.adapt_vector(self.rows[k], x, self.orc.gaussian_h(dd, trad, talp))
@@ -74,19 +75,27 @@ def _worker(rank, world, port, q):
     try:
         orc = Oracle()
         out = {}
-        for case, (xdim, ydim, topol, neigh, B, length) in enumerate([(8, 6, 3, 1, 16, 160), (7, 5, 4, 2, 8, 96)]):
+        cases = [(8, 6, 3, 1, 16, 160, False), (7, 5, 4, 2, 8, 96, False), (24, 8, 3, 1, 16, 96, True)]
+        for case, (xdim, ydim, topol, neigh, B, length, interleaved) in enumerate(cases):
             x, _ = synth(50 + case, 70, 6)
             ini = orc.randinit(x, xdim, ydim, 2 + case)
             n = xdim * ydim
-            r0, r1 = sharded.shard_rows(n, world, rank)
-            sh = CheckerShard(orc, ini[r0:r1], r0, n, xdim, topol, neigh, x, length, 0.09, 3.0)
+            if interleaved:          # the layout bench.py uses for N > 1: 8x8 patches dealt round-robin (3 patches, 2 ranks)
+                from som_lvq_pak_amd import engine as E
+                units = E.shard_units(xdim, ydim, rank, world)
+            else:
+                r0, r1 = sharded.shard_rows(n, world, rank)
+                units = np.arange(r0, r1)
+            sh = CheckerShard(orc, ini[units], units, n, xdim, topol, neigh, x, length, 0.09, 3.0)
             som = sharded.ShardedSom(sh, B, x.shape[0])
             winners = som.train(length)
             widx = np.concatenate([sharded.unpack_keys(w.numpy())[1] for w in winners])
             gathered = [None] * world
-            dist.all_gather_object(gathered, (r0, sh.rows))
+            dist.all_gather_object(gathered, (units, sh.rows))
             if rank == 0:
-                full = np.concatenate([g[1] for g in sorted(gathered, key=lambda t: t[0])], axis=0)
+                full = np.empty_like(ini)
+                for u, r in gathered:
+                    full[u] = r
                 want, wi, _ = orc.som_train(ini, xdim, ydim, topol, neigh, x, length, 0.09, 3.0, batch=B)
                 out[case] = (bool(np.array_equal(full.view(np.uint32), want.view(np.uint32))),
                              bool(np.array_equal(widx, wi)))
@@ -128,6 +137,7 @@ def test_sharded_training_world2_gloo():
         assert p.exitcode == 0
     assert out[0] == (True, True)
     assert out[1] == (True, True)
+    assert out[2] == (True, True)          # interleaved patches
     assert out["none_key"] == [5, 7]
     assert out["knn"] == (True, True)
 
