@@ -53,6 +53,8 @@ def parse():
                     help="winner-search implementation (all bit-identical); auto = the engine's default")
     ap.add_argument("--force-sharded-path", action="store_true",
                     help="N=1 only: drive the two-phase step from Python as the N>1 path does (host-overhead check)")
+    ap.add_argument("--neigh", default="bubble", choices=["bubble", "gaussian"],
+                    help="neighbourhood kernel (the headline workload is bubble; gaussian updates every unit for every vector)")
     ap.add_argument("--shards", default="interleaved", choices=["interleaved", "contiguous"],
                     help="N > 1: how the map's units are dealt to the ranks")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -121,16 +123,17 @@ def main():
         eng.set_scan_mode(a.scan)
     ds = E.Dataset(eng, device_ptr=data.data_ptr(), n=nvec, dim=d)
     from som_lvq_pak_amd.sharded import shard_rows
+    neigh = E.NEIGH_GAUSSIAN if a.neigh == "gaussian" else E.NEIGH_BUBBLE
     if a.shards == "interleaved" and world > 1 and xdim % 8 == 0 and ydim % 8 == 0:
         # 8x8-unit patches dealt round-robin to the ranks: every rank sees every region of the map, so the
         # neighbourhood updates of a batch are spread evenly whatever the radius (include/somhip.h)
         mine = E.shard_units(xdim, ydim, rank, world, eng.lib)
-        cb = E.Codebook(eng, init[mine], E.TOPOL_HEXA, E.NEIGH_BUBBLE, xdim, ydim, interleave=(rank, world))
+        cb = E.Codebook(eng, init[mine], E.TOPOL_HEXA, neigh, xdim, ydim, interleave=(rank, world))
         layout = "8x8-unit patches interleaved over %d ranks" % world
     else:
         r0, r1 = shard_rows(N, world, rank)
         mine = np.arange(r0, r1)
-        cb = E.Codebook(eng, init[r0:r1], E.TOPOL_HEXA, E.NEIGH_BUBBLE, xdim, ydim, row_offset=r0, n_global=N)
+        cb = E.Codebook(eng, init[r0:r1], E.TOPOL_HEXA, neigh, xdim, ydim, row_offset=r0, n_global=N)
         layout = "contiguous row blocks /%d" % world
     lib = eng.lib
 
@@ -297,7 +300,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "final_qerror": qerr,
             "config": {"workload": "vsom 256x256 hexa bubble SOM, dim=512 (BASELINE.json configs[3])"
-                       if (xdim, ydim, d) == (256, 256, 512) else "vsom %dx%d hexa bubble SOM, dim=%d" % (xdim, ydim, d),
+                       if (xdim, ydim, d, a.neigh) == (256, 256, 512, "bubble")
+                       else "vsom %dx%d hexa %s SOM, dim=%d" % (xdim, ydim, a.neigh, d),
                        "dim": d, "codebook_rows": N, "batch": B, "vectors": K * B, "alpha": a.alpha,
                        "radius": radius, "alpha_type": "linear",
                        "schedule": "mini-batch (winners per batch, in-order updates)" if B > 1 else "online (reference-exact)",
@@ -338,12 +342,12 @@ def cpu_baseline(a, init, data, xdim, ydim, d, radius):
     t0 = time.perf_counter()
     if oracle.ref_available():
         ref = oracle.RefHarness()
-        ref.som_train(init, xdim, ydim, 3, 1, x, n, a.alpha, radius, trace=False)
+        ref.som_train(init, xdim, ydim, 3, 2 if a.neigh == "gaussian" else 1, x, n, a.alpha, radius, trace=False)
         secs, kind = ref.last_seconds, "reference"
     else:
         orc = oracle.Oracle()
         t0 = time.perf_counter()
-        orc.som_train(init, xdim, ydim, 3, 1, x, n, a.alpha, radius, trace=False)
+        orc.som_train(init, xdim, ydim, 3, 2 if a.neigh == "gaussian" else 1, x, n, a.alpha, radius, trace=False)
         secs, kind = time.perf_counter() - t0, "port"
     return {"value": n / secs, "unit": "vectors/s", "cores": 1, "kind": kind,
             "host_cores": os.cpu_count(),

