@@ -112,6 +112,13 @@ int  somhip_dataset_create(somhip_engine *e, const float *rows, int64_t n_rows, 
  * used in place, not copied (bench / streaming ingest) */
 int  somhip_dataset_wrap_device(somhip_engine *e, const float *dev_rows, int64_t n_rows, int dim,
                                 somhip_dataset **out);
+/* a data set generated in place: rows [first_row, first_row + n_rows) of the seeded Gaussian-mixture stream
+ * (k_centres centres 4z, row = centre[k(row)] + z, z = sum of twelve 16-bit uniforms - 6: counter-based
+ * and exact, so it equals the host form bit for bit -- `-din gen:k=..,dim=..,n=..,seed=..` in the C tools,
+ * pak_gen_row in som_lvq_pak_amd/host/paklib.c).  centres (host, may be NULL) receives each row's mixture id,
+ * which also becomes the data set's labels.  No host copy, no PCIe: what the C4/C5-sized runs need. */
+int  somhip_dataset_generate(somhip_engine *e, uint64_t seed, int k_centres, int dim, int64_t first_row,
+                             int64_t n_rows, int32_t *centres, somhip_dataset **out);
 void somhip_dataset_destroy(somhip_dataset *ds);
 
 /* ---- winner scans: WINNER_FUNCTION over a run of samples (lvq_pak.h:146) -----

@@ -57,6 +57,8 @@ SIGNATURES = {
     "somhip_codebook_destroy": (None, [C.c_void_p]),
     "somhip_dataset_create": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, C.c_int, c_u8_p, c_i32_p,
                                         c_i16_p, c_i16_p, C.POINTER(C.c_void_p)]),
+    "somhip_dataset_generate": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, c_i32_p,
+                                          C.POINTER(C.c_void_p)]),
     "somhip_dataset_wrap_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                              C.POINTER(C.c_void_p)]),
     "somhip_dataset_destroy": (None, [C.c_void_p]),

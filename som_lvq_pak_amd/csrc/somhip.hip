@@ -495,6 +495,34 @@ extern "C" int somhip_dataset_wrap_device(somhip_engine *e, const float *dev_row
   *out = ds;
   return 0;
 }
+extern "C" int somhip_dataset_generate(somhip_engine *e, uint64_t seed, int k_centres, int dim, int64_t first_row,
+                                       int64_t n_rows, int32_t *centres, somhip_dataset **out) {
+  if (!e || !out) return fail("somhip_dataset_generate: null argument");
+  if (k_centres <= 0 || dim <= 0 || n_rows <= 0 || first_row < 0) return fail("somhip_dataset_generate: bad shape");
+  HIPCHK(hipSetDevice(e->device));
+  somhip_dataset *ds = new somhip_dataset();
+  ds->e = e; ds->n = n_rows; ds->d = dim; ds->owns_rows = true;
+  float *rows = nullptr;
+  int32_t *dcen = nullptr;
+  HIPCHK(hipMalloc((void **)&rows, sizeof(float) * (size_t)n_rows * dim));
+  ds->d_rows = rows;
+  if (centres) HIPCHK(hipMalloc((void **)&dcen, sizeof(int32_t) * (size_t)n_rows));
+  const int64_t total = n_rows * dim;
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65536);
+  {
+    LaunchTimer t(e, KID_LAYOUT);
+    hipLaunchKernelGGL(k_gen_mixture, dim3(blocks), dim3(256), 0, e->stream, seed, k_centres, dim, first_row, n_rows, rows, dcen);
+  }
+  HIPCHK(hipGetLastError());
+  if (centres) {
+    HIPCHK(hipMemcpyAsync(centres, dcen, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    ds->labels.assign(centres, centres + n_rows);
+    HIPCHK(hipFree(dcen));
+  }
+  *out = ds;
+  return 0;
+}
 extern "C" void somhip_dataset_destroy(somhip_dataset *ds) {
   if (!ds) return;
   (void)hipSetDevice(ds->e->device);

@@ -175,10 +175,18 @@ class Dataset:
     """Device mirror of the `data` list (one -buffer worth of rows)."""
 
     def __init__(self, engine, rows=None, mask=None, labels=None, weight=None, fixed_xy=None,
-                 device_ptr=None, n=None, dim=None):
+                 device_ptr=None, n=None, dim=None, generate=None):
+        """generate=(seed, k_centres, dim, first_row, n_rows): the seeded mixture stream made in HBM
+        (somhip_dataset_generate); self.centres then holds each row's mixture id."""
         self.e = engine
         h = C.c_void_p()
-        if device_ptr is not None:
+        if generate is not None:
+            seed, k, gdim, first, gn = generate
+            self.n, self.dim = gn, gdim
+            self.centres = np.empty(gn, dtype=np.int32)
+            check(engine.lib.somhip_dataset_generate(engine.h, seed, k, gdim, first, gn,
+                                                     _p(self.centres, _lib.c_i32_p), C.byref(h)))
+        elif device_ptr is not None:
             self.n, self.dim = n, dim
             check(engine.lib.somhip_dataset_wrap_device(engine.h, C.c_void_p(device_ptr), n, dim, C.byref(h)))
         else:
@@ -205,6 +213,34 @@ class Dataset:
             self.close()
         except Exception:
             pass
+
+
+def gen_rows(seed, k_centres, dim, first_row, n_rows):
+    """Host form of the seeded mixture stream (numpy restatement of pak_gen_row / k_gen_mixture): (rows, centres)."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def mix(x):
+        with np.errstate(over="ignore"):
+            x = (x + np.uint64(0x9E3779B97F4A7C15)) & M
+            x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M
+            x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M
+            return x ^ (x >> np.uint64(31))
+
+    def z(sd, counter):
+        total = np.zeros(counter.shape, dtype=np.int64)
+        with np.errstate(over="ignore"):
+            for w in range(3):
+                v = mix(np.uint64(sd) ^ (np.uint64(3) * counter + np.uint64(w)))
+                for sh in (0, 16, 32, 48):
+                    total += ((v >> np.uint64(sh)) & np.uint64(0xFFFF)).astype(np.int64)
+        return ((total - 6 * 65535).astype(np.float32) / np.float32(65536.0)).astype(np.float32)
+
+    rows = np.arange(first_row, first_row + n_rows, dtype=np.uint64)
+    cen = (mix(np.uint64(seed ^ 0xB492B66FBE98F273) ^ rows) % np.uint64(k_centres)).astype(np.int64)
+    cols = np.arange(dim, dtype=np.uint64)[None, :]
+    mu = np.float32(4.0) * z(seed ^ 0xC3A5C85C97CB3127, cen.astype(np.uint64)[:, None] * np.uint64(dim) + cols)
+    x = mu + z(seed, rows[:, None] * np.uint64(dim) + cols)
+    return x.astype(np.float32), cen.astype(np.int32)
 
 
 def find_winners(cb, ds, first=0, count=None, knn=1, tie=TIE_FIRST):

@@ -13,6 +13,7 @@
 #define PAK_H
 
 #include <stdio.h>
+#include <stdint.h>
 #include "somhip.h"
 
 /* ids as in the reference (lvq_pak.h:209-224) */
@@ -114,6 +115,13 @@ int pak_parse_float(const char *s, float *out);     /* = sscanf(s, "%f", out) > 
 struct entries *open_entries(const char *name, int labels_needed, int skip_empty);
 int save_entries_wcomments(struct entries *codes, const char *name, const char *comments);
 #define save_entries(c, n) save_entries_wcomments((c), (n), NULL)
+/* raw fp32 side format ("#!somf32", paklib.c) -- open_entries reads it transparently, this writes it */
+int save_entries_f32(struct entries *c, const char *name);
+/* the seeded Gaussian-mixture stream behind `-din gen:k=..,dim=..,n=..,seed=..[,labels=1]` (paklib.c) */
+uint64_t pak_splitmix64(uint64_t x);
+float pak_gen_z(uint64_t seed, uint64_t counter);
+void pak_gen_row(uint64_t seed, int k_centres, int dim, long row, float *out, int *centre);
+int pak_parse_gen(const char *spec, long *n, int *dim, int *k, uint64_t *seed, int *labels);
 void close_entries(struct entries *);
 void clear_entry_labels(struct entries *e, long row);
 void add_entry_label(struct entries *e, long row, int label);

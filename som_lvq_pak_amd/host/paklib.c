@@ -205,6 +205,236 @@ slow:
   return sscanf(s, "%f", out) > 0;
 }
 
+/* what may follow the numbers of a row: labels, weight=N, fixed=X,Y (datafile.c:705-735) */
+static int row_tokens(struct entries *e, long r, char *tok, char **save, struct fixpoint *fix, int *any_weight,
+                      int *any_fixed, int labels_needed, long lineno, const char *name)
+{
+  struct data_entry *d = &e->rows[r];
+  int label_found = 0;
+  for (; tok; tok = strtok_r(NULL, " \r\t", save)) {
+    if (strncmp(tok, "weight=", 7) == 0) { d->weight = (short)atoi(tok + 7); *any_weight = 1; }
+    else if (strncmp(tok, "fixed=", 6) == 0) {
+      char *comma = strchr(tok, ',');
+      if (!comma) { fprintf(stderr, "bad fixed point, line %ld of file %s\n", lineno, name); return 1; }
+      fix->xfix = (short)atoi(tok + 6);
+      fix->yfix = (short)atoi(comma + 1);
+      *any_fixed = 1;
+    } else {
+      add_entry_label(e, r, find_conv_to_ind(tok));
+      label_found++;
+    }
+  }
+  if (labels_needed && !label_found) {
+    fprintf(stderr, "Required label missing on line %ld of file %s\n", lineno, name);
+    return 1;
+  }
+  return 0;
+}
+
+static int parse_header(struct entries *e, const char *line, const char *name)
+{
+  int dim = 0;
+  if (sscanf(line, "%d", &dim) <= 0 || dim <= 0) {
+    fprintf(stderr, "Can't read dimension parameter in file %s", name);
+    return 0;
+  }
+  char *save, *dup = strdup(line);
+  strtok_r(dup, " ", &save);
+  char *t = strtok_r(NULL, " ", &save);
+  char *xs = strtok_r(NULL, " ", &save), *ys = strtok_r(NULL, " ", &save), *ns = strtok_r(NULL, " ", &save);
+  e->dimension = (short)dim;
+  e->topol = (short)id_of(topol_names, 5, t);
+  e->xdim = xs ? (short)atoi(xs) : 0;
+  e->ydim = ys ? (short)atoi(ys) : 0;
+  e->neigh = (short)id_of(neigh_names, 3, ns);
+  free(dup);
+  return dim;
+}
+
+/* dense side arrays + row views once all rows are in e->points (maskrows / fixtmp may be NULL) */
+static void finish_entries(struct entries *e, char **maskrows, struct fixpoint *fixtmp, int any_fixed, int any_weight)
+{
+  long n = e->num_entries;
+  int dim = e->dimension, any_mask = 0;
+  for (long r = 0; maskrows && r < n; r++) any_mask |= maskrows[r] != NULL;
+  if (any_mask) e->masks = calloc((size_t)n * dim + 1, 1);
+  if (any_fixed) e->fixed_xy = malloc(sizeof(short) * 2 * (n + 1));
+  if (any_weight) e->weights = malloc(sizeof(short) * (n + 1));
+  for (long r = 0; r < n; r++) {
+    struct data_entry *d = &e->rows[r];
+    d->points = e->points + r * dim;
+    if (any_mask && maskrows[r]) { memcpy(e->masks + r * dim, maskrows[r], dim); d->mask = e->masks + r * dim; }
+    if (maskrows) free(maskrows[r]);
+    if (any_fixed) {
+      e->fixed_xy[2 * r] = fixtmp[r].xfix; e->fixed_xy[2 * r + 1] = fixtmp[r].yfix;
+      if (fixtmp[r].xfix >= 0) d->fixed = (struct fixpoint *)(e->fixed_xy + 2 * r);
+    }
+    if (any_weight) e->weights[r] = d->weight;
+  }
+}
+
+/* ---- raw fp32 side format (the text parser is the wall once the kernels are fast) ----
+ *   line 1   "#!somf32 <rows> <flags>"         flags bit 0: a text section follows the numbers
+ *   line 2   the .dat header line              "<dim> [topol [xdim ydim neigh]]"  (datafile.c:396-415)
+ *   payload  rows * dim little-endian float32  NaN = masked component (the 'x' of the text format)
+ *   text     (flag bit 0) one line per row with what follows the numbers in a .dat row: labels, weight=, fixed=
+ * Read with one fread straight into the dense array; rows whose components are all masked are dropped as in
+ * the text reader.  `datconv` converts both ways. */
+static struct entries *read_f32(FILE *fp, const char *first_line, const char *name, int labels_needed, int skip_empty)
+{
+  long n = 0;
+  int flags = 0;
+  if (sscanf(first_line, "#!somf32 %ld %d", &n, &flags) < 1 || n < 0) { fprintf(stderr, "bad somf32 header in file %s\n", name); return NULL; }
+  struct entries *e = calloc(1, sizeof *e);
+  e->labels_needed = labels_needed;
+  char *line = NULL;
+  size_t cap = 0;
+  struct fixpoint *fixtmp = NULL;
+  char **maskrows = NULL;
+  int any_fixed = 0, any_weight = 0, dim;
+  if (getline(&line, &cap, fp) < 0 || !(dim = parse_header(e, line, name))) goto fail;
+  e->points = malloc(sizeof(float) * (size_t)(n ? n : 1) * dim);
+  e->rows = calloc((size_t)(n ? n : 1), sizeof(struct data_entry));
+  if (fread(e->points, sizeof(float) * dim, (size_t)n, fp) != (size_t)n) { fprintf(stderr, "file %s is shorter than its header says\n", name); goto fail; }
+  maskrows = calloc((size_t)(n ? n : 1), sizeof(char *));
+  fixtmp = malloc(sizeof(struct fixpoint) * (size_t)(n ? n : 1));
+  long kept = 0;
+  for (long r = 0; r < n; r++) {                    /* NaN -> mask; drop empty rows; compact in place */
+    float *p = e->points + r * dim;
+    char *mask = NULL;
+    int maskcnt = 0;
+    for (int i = 0; i < dim; i++)
+      if (p[i] != p[i]) { if (!mask) mask = calloc(dim, 1); mask[i] = 1; maskcnt++; p[i] = 0.0f; }
+    char *tokline = NULL, *save = NULL, *tok = NULL;
+    if (flags & 1) {
+      if (getline(&line, &cap, fp) < 0) { fprintf(stderr, "file %s: text section ends at row %ld\n", name, r); free(mask); goto fail; }
+      size_t L = strlen(line);
+      if (L && line[L - 1] == '\n') line[--L] = 0;
+      tokline = line;
+    }
+    if (maskcnt == dim && skip_empty) { free(mask); continue; }
+    if (kept != r) memmove(e->points + kept * dim, p, sizeof(float) * dim);
+    maskrows[kept] = mask;
+    fixtmp[kept].xfix = fixtmp[kept].yfix = -1;
+    e->num_entries = kept + 1;
+    if (tokline) tok = strtok_r(tokline, " \r\t", &save);
+    if (row_tokens(e, kept, tok, &save, &fixtmp[kept], &any_weight, &any_fixed, labels_needed, r + 3, name)) goto fail;
+    kept++;
+  }
+  e->num_entries = kept;
+  finish_entries(e, maskrows, fixtmp, any_fixed, any_weight);
+  free(maskrows); free(fixtmp); free(line);
+  return e;
+fail:
+  free(maskrows); free(fixtmp); free(line);
+  close_entries(e);
+  return NULL;
+}
+
+int save_entries_f32(struct entries *c, const char *name)
+{
+  int is_pipe, any_text = 0;
+  for (long r = 0; r < c->num_entries && !any_text; r++)
+    any_text = c->rows[r].num_labs > 0 || c->rows[r].weight != 0 || c->rows[r].fixed != NULL;
+  FILE *fp = open_text(name, "w", &is_pipe);
+  if (!fp) { fprintf(stderr, "Can't open file %s for writing\n", name); return 1; }
+  fprintf(fp, "#!somf32 %ld %d\n%d", c->num_entries, any_text, c->dimension);
+  if (c->topol > TOPOL_DATA) {
+    fprintf(fp, " %s", topol_names[c->topol]);
+    if (c->topol > TOPOL_LVQ) fprintf(fp, " %d %d %s", c->xdim, c->ydim, neigh_names[c->neigh] ? neigh_names[c->neigh] : "");
+  }
+  fputc('\n', fp);
+  const int dim = c->dimension;
+  float *tmp = malloc(sizeof(float) * dim);
+  for (long r = 0; r < c->num_entries; r++) {
+    const struct data_entry *d = &c->rows[r];
+    if (d->mask) {
+      for (int i = 0; i < dim; i++) tmp[i] = d->mask[i] ? __builtin_nanf("") : d->points[i];
+      fwrite(tmp, sizeof(float), dim, fp);
+    } else fwrite(d->points, sizeof(float), dim, fp);
+  }
+  free(tmp);
+  for (long r = 0; any_text && r < c->num_entries; r++) {
+    const struct data_entry *d = &c->rows[r];
+    for (int k = 0; k < d->num_labs; k++) fprintf(fp, "%s ", find_conv_to_lab(d->labels[k]));
+    if (d->weight) fprintf(fp, "weight=%d ", d->weight);
+    if (d->fixed) fprintf(fp, "fixed=%d,%d ", d->fixed->xfix, d->fixed->yfix);
+    fputc('\n', fp);
+  }
+  int bad = ferror(fp);
+  close_text(fp, is_pipe);
+  return bad;
+}
+
+/* ---- seeded generator as a data source:  -din gen:k=256,dim=512,n=100000,seed=3456[,labels=1] ----
+ * The Gaussian-mixture stream of SURVEY 8(d), counter-based so that any row can be produced anywhere (host here,
+ * k_gen_mixture on the device: same bits, tests/test_gpu_parity.py):  splitmix64(seed ^ counter) words; a centre
+ * component is 4 z, a sample is centre[k(row)] + z with k(row) = word(seed_assign ^ row) mod K; z is the classic
+ * sum of twelve uniforms minus six, here twelve 16-bit fields of three words: integer arithmetic and one exact
+ * division by 65536, so host and device cannot differ (a Box-Muller z would depend on each side's log and cos).
+ * labels=1 attaches the mixture id ("c<k>") as the row's label. */
+uint64_t pak_splitmix64(uint64_t x)
+{
+  x += 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+float pak_gen_z(uint64_t seed, uint64_t counter)
+{
+  int32_t sum = 0;
+  for (int w = 0; w < 3; w++) {
+    uint64_t v = pak_splitmix64(seed ^ (3 * counter + w));
+    sum += (int32_t)(v & 0xFFFF) + (int32_t)((v >> 16) & 0xFFFF) + (int32_t)((v >> 32) & 0xFFFF) + (int32_t)(v >> 48);
+  }
+  return (float)(sum - 6 * 65535) / 65536.0f;      /* |sum - 393210| < 2^24: exact */
+}
+void pak_gen_row(uint64_t seed, int k_centres, int dim, long row, float *out, int *centre)
+{
+  const uint64_t seed_c = seed ^ 0xC3A5C85C97CB3127ULL, seed_a = seed ^ 0xB492B66FBE98F273ULL;
+  const int k = (int)(pak_splitmix64(seed_a ^ (uint64_t)row) % (uint64_t)k_centres);
+  for (int i = 0; i < dim; i++) {
+    const float mu = 4.0f * pak_gen_z(seed_c, (uint64_t)k * dim + i);
+    out[i] = mu + pak_gen_z(seed, (uint64_t)row * dim + i);
+  }
+  if (centre) *centre = k;
+}
+int pak_parse_gen(const char *spec, long *n, int *dim, int *k, uint64_t *seed, int *labels)
+{
+  if (strncmp(spec, "gen:", 4) != 0) return 0;
+  *n = 0; *dim = 0; *k = 16; *seed = 1234; *labels = 0;
+  char *dup = strdup(spec + 4), *save, *tok;
+  for (tok = strtok_r(dup, ",", &save); tok; tok = strtok_r(NULL, ",", &save)) {
+    if (sscanf(tok, "n=%ld", n) == 1 || sscanf(tok, "dim=%d", dim) == 1 || sscanf(tok, "k=%d", k) == 1 ||
+        sscanf(tok, "labels=%d", labels) == 1) continue;
+    unsigned long long sv;
+    if (sscanf(tok, "seed=%llu", &sv) == 1) { *seed = sv; continue; }
+    fprintf(stderr, "gen: unknown field '%s' (n=, dim=, k=, seed=, labels=)\n", tok);
+    free(dup);
+    return -1;
+  }
+  free(dup);
+  if (*n <= 0 || *dim <= 0 || *dim > 32767 || *k <= 0) { fprintf(stderr, "gen: needs n=, dim= (and k > 0)\n"); return -1; }
+  return 1;
+}
+static struct entries *gen_entries(const char *spec)
+{
+  long n; int dim, k, labels; uint64_t seed;
+  if (pak_parse_gen(spec, &n, &dim, &k, &seed, &labels) <= 0) return NULL;
+  struct entries *e = calloc(1, sizeof *e);
+  e->dimension = (short)dim;
+  e->num_entries = n;
+  e->points = malloc(sizeof(float) * (size_t)n * dim);
+  e->rows = calloc((size_t)n, sizeof(struct data_entry));
+  for (long r = 0; r < n; r++) {
+    int c;
+    pak_gen_row(seed, k, dim, r, e->points + r * dim, &c);
+    if (labels) { char nm[32]; snprintf(nm, sizeof nm, "c%d", c); add_entry_label(e, r, find_conv_to_ind(nm)); }
+  }
+  finish_entries(e, NULL, NULL, 0, 0);
+  return e;
+}
+
 /* open_entries + read_entries (datafile.c:191,237) for a whole file.  Header: first
  * non-comment line "<dim> [topol [xdim ydim neigh]]" (datafile.c:112-145).  Rows: <dim>
  * numbers or the mask string, then labels / weight=N / fixed=X,Y (datafile.c:552-748);
@@ -213,6 +443,7 @@ slow:
 struct entries *open_entries(const char *name, int labels_needed, int skip_empty)
 {
   int is_pipe;
+  if (strncmp(name, "gen:", 4) == 0) return gen_entries(name);
   FILE *fp = open_text(name, "r", &is_pipe);
   if (!fp) { fprintf(stderr, "Can't open file %s", name); return NULL; }
   struct entries *e = calloc(1, sizeof *e);
@@ -229,22 +460,15 @@ struct entries *open_entries(const char *name, int labels_needed, int skip_empty
     lineno++;
     size_t L = strlen(line);
     if (L && line[L - 1] == '\n') line[--L] = 0;
+    if (lineno == 1 && strncmp(line, "#!somf32", 8) == 0) {      /* the raw fp32 side format */
+      struct entries *b = read_f32(fp, line, name, labels_needed, skip_empty);
+      free(line); free(e);
+      close_text(fp, is_pipe);
+      return b;
+    }
     if (line[0] == '#') continue;
     if (!have_header) {
-      if (sscanf(line, "%d", &dim) <= 0) {
-        fprintf(stderr, "Can't read dimension parameter in file %s", name);
-        goto fail;
-      }
-      char *save, *dup = strdup(line);
-      strtok_r(dup, " ", &save);
-      char *t = strtok_r(NULL, " ", &save);
-      char *xs = strtok_r(NULL, " ", &save), *ys = strtok_r(NULL, " ", &save), *ns = strtok_r(NULL, " ", &save);
-      e->dimension = (short)dim;
-      e->topol = (short)id_of(topol_names, 5, t);
-      e->xdim = xs ? (short)atoi(xs) : 0;
-      e->ydim = ys ? (short)atoi(ys) : 0;
-      e->neigh = (short)id_of(neigh_names, 3, ns);
-      free(dup);
+      if (!(dim = parse_header(e, line, name))) goto fail;
       have_header = 1;
       continue;
     }
@@ -282,48 +506,11 @@ struct entries *open_entries(const char *name, int labels_needed, int skip_empty
     maskrows[r] = mask;
     fixtmp[r].xfix = fixtmp[r].yfix = -1;
     e->num_entries++;
-    int label_found = 0;
-    while ((tok = strtok_r(NULL, " \r\t", &save)) != NULL) {
-      if (strncmp(tok, "weight=", 7) == 0) { d->weight = (short)atoi(tok + 7); any_weight = 1; }
-      else if (strncmp(tok, "fixed=", 6) == 0) {
-        char *comma = strchr(tok, ',');
-        if (!comma) { fprintf(stderr, "bad fixed point, line %ld of file %s\n", lineno, name); goto fail; }
-        fixtmp[r].xfix = (short)atoi(tok + 6);
-        fixtmp[r].yfix = (short)atoi(comma + 1);
-        any_fixed = 1;
-      } else {
-        add_entry_label(e, r, find_conv_to_ind(tok));
-        label_found++;
-      }
-    }
-    if (labels_needed && !label_found) {
-      fprintf(stderr, "Required label missing on line %ld of file %s\n", lineno, name);
-      goto fail;
-    }
+    tok = strtok_r(NULL, " \r\t", &save);
+    if (row_tokens(e, r, tok, &save, &fixtmp[r], &any_weight, &any_fixed, labels_needed, lineno, name)) goto fail;
   }
   if (!have_header) { fprintf(stderr, "Can't read file %s", name); goto fail; }
-  /* dense side arrays + row views */
-  {
-    long n = e->num_entries;
-    int any_mask = 0;
-    for (long r = 0; r < n; r++) any_mask |= maskrows[r] != NULL;
-    if (any_mask) e->masks = calloc((size_t)n * dim + 1, 1);
-    if (any_fixed) e->fixed_xy = malloc(sizeof(short) * 2 * (n + 1));
-    if (any_weight) e->weights = malloc(sizeof(short) * (n + 1));
-    for (long r = 0; r < n; r++) {
-      struct data_entry *d = &e->rows[r];
-      d->points = e->points + r * dim;
-      if (any_mask) {
-        if (maskrows[r]) { memcpy(e->masks + r * dim, maskrows[r], dim); d->mask = e->masks + r * dim; }
-      }
-      free(maskrows[r]);
-      if (any_fixed) {
-        e->fixed_xy[2 * r] = fixtmp[r].xfix; e->fixed_xy[2 * r + 1] = fixtmp[r].yfix;
-        if (fixtmp[r].xfix >= 0) d->fixed = (struct fixpoint *)(e->fixed_xy + 2 * r);
-      }
-      if (any_weight) e->weights[r] = d->weight;
-    }
-  }
+  finish_entries(e, maskrows, fixtmp, any_fixed, any_weight);
   free(maskrows); free(fixtmp); free(line);
   close_text(fp, is_pipe);
   return e;

@@ -304,3 +304,87 @@ def test_whole_somexample_on_these_tools(tools, tmp_path):
     vis = tmp_path / "ex.vis"
     run("visual", "-din", os.path.join(DATA, "ex_fts.dat"), "-cin", cod, "-dout", vis, "-v", 0)
     assert md5(vis) == EXPECTED["som"]["somexample_vis_md5"]
+
+
+# ------------------------------------------------------------------ raw fp32 side format + generator source
+def _f32_payload(path):
+    raw = open(path, "rb").read()
+    head_end = raw.index(b"\n", raw.index(b"\n") + 1) + 1
+    first = raw[:raw.index(b"\n")].split()
+    dim = int(raw[raw.index(b"\n") + 1:head_end].split()[0])
+    n = int(first[1])
+    import numpy as np
+    x = np.frombuffer(raw[head_end:head_end + 4 * n * dim], dtype=np.float32).reshape(n, dim)
+    return x, raw[head_end + 4 * n * dim:].decode()
+
+
+def test_datconv_raw_fp32_roundtrip(tools, tmp_path):
+    """text -> raw fp32 keeps every number the text reader produced (sscanf("%f") semantics), masks ride
+    as NaN, labels / weight= / fixed= in the trailing text section; raw -> raw is the identity and raw -> text prints what text -> text prints."""
+    import numpy as np
+    ex = os.path.join(DATA, "ex.dat")
+    run("datconv", "-din", ex, "-dout", tmp_path / "ex.f32")
+    x, tail = _f32_payload(tmp_path / "ex.f32")
+    want = np.array([[np.float32(t) for t in ln.split()[:5]] for ln in open(ex) if not ln.startswith("#")][1:], dtype=np.float32)
+    assert tail == "" and np.array_equal(x.view(np.uint32), want.view(np.uint32))
+    for name in ("ex_masked.dat", "ex_fts.dat", "ex1.dat"):
+        src = os.path.join(DATA, name)
+        run("datconv", "-din", src, "-dout", tmp_path / "a.txt", "-text", "-noskip")
+        run("datconv", "-din", src, "-dout", tmp_path / "a.f32", "-noskip")
+        run("datconv", "-din", tmp_path / "a.f32", "-dout", tmp_path / "b.txt", "-text", "-noskip")
+        run("datconv", "-din", tmp_path / "a.f32", "-dout", tmp_path / "b.f32", "-noskip")
+        assert md5(tmp_path / "a.txt") == md5(tmp_path / "b.txt"), name          # raw -> text == text -> text ("%g")
+        assert md5(tmp_path / "a.f32") == md5(tmp_path / "b.f32"), name          # raw -> raw is the identity
+    xm, tailm = _f32_payload(tmp_path / "a.f32")
+    assert len(tailm.splitlines()) == xm.shape[0]                    # ex1.dat: one label line per row
+
+
+def test_generator_source_equals_its_restatement(tools, tmp_path):
+    """-din gen:... (paklib.c pak_gen_row) against the numpy restatement in engine.gen_rows, bit for bit, and
+    the stream does not depend on where a window starts."""
+    import numpy as np
+    from som_lvq_pak_amd import engine as E
+    run("datconv", "-din", "gen:k=7,dim=13,n=300,seed=4242,labels=1", "-dout", tmp_path / "g.f32")
+    x, tail = _f32_payload(tmp_path / "g.f32")
+    gx, gc = E.gen_rows(4242, 7, 13, 0, 300)
+    assert np.array_equal(x.view(np.uint32), gx.view(np.uint32))
+    assert [int(t[1:]) for t in tail.split()] == gc.tolist()
+    wx, wc = E.gen_rows(4242, 7, 13, 100, 50)
+    assert np.array_equal(wx.view(np.uint32), gx[100:150].view(np.uint32)) and np.array_equal(wc, gc[100:150])
+    assert abs(float(gx.mean())) < 1.5 and 2.5 < float(gx.std()) < 5.5     # 4 z centres + unit noise
+    assert run("datconv", "-din", "gen:dim=3", "-dout", tmp_path / "bad", check=False).returncode != 0
+
+
+@pytest.mark.gpu
+def test_tools_read_raw_fp32_like_text(tools, tmp_path):
+    """vsom / qerror on ex.f32 give the bytes the reference gave on ex.dat; lvq1 / accuracy on the labelled
+    ex1/ex2 pair likewise."""
+    run("datconv", "-din", os.path.join(DATA, "ex.dat"), "-dout", tmp_path / "ex.f32")
+    ex = EXPECTED["som"]["hexa_bubble"]
+    out = tmp_path / "out.cod"
+    run("vsom", "-din", tmp_path / "ex.f32", "-cin", os.path.join(CLI, ex["init"]), "-cout", out,
+        "-rlen", ex["rlen"], "-alpha", ex["alpha"], "-radius", ex["radius"], "-v", 0)
+    assert md5(out) == ex["md5"]
+    assert run("qerror", "-din", tmp_path / "ex.f32", "-cin", out, "-v", 0).stdout == ex["qerror_stdout"]
+    for name in ("ex1", "ex2"):
+        run("datconv", "-din", os.path.join(DATA, name + ".dat"), "-dout", tmp_path / (name + ".f32"))
+    run("eveninit", "-din", tmp_path / "ex1.f32", "-cout", tmp_path / "a.cod", "-noc", 200, "-v", 0)
+    run("eveninit", "-din", os.path.join(DATA, "ex1.dat"), "-cout", tmp_path / "b.cod", "-noc", 200, "-v", 0)
+    assert md5(tmp_path / "a.cod") == md5(tmp_path / "b.cod")
+    run("lvq1", "-din", tmp_path / "ex1.f32", "-cin", tmp_path / "a.cod", "-cout", tmp_path / "a1.cod", "-rlen", 2000, "-alpha", 0.05, "-v", 0)
+    run("lvq1", "-din", os.path.join(DATA, "ex1.dat"), "-cin", tmp_path / "b.cod", "-cout", tmp_path / "b1.cod", "-rlen", 2000, "-alpha", 0.05, "-v", 0)
+    assert md5(tmp_path / "a1.cod") == md5(tmp_path / "b1.cod")
+    pa = run("accuracy", "-din", tmp_path / "ex2.f32", "-cin", tmp_path / "a1.cod", "-v", 0).stdout
+    pb = run("accuracy", "-din", os.path.join(DATA, "ex2.dat"), "-cin", tmp_path / "b1.cod", "-v", 0).stdout
+    assert pa == pb and "Total accuracy" in pa or pa == pb
+
+
+@pytest.mark.gpu
+def test_vsom_on_generated_source(tools, tmp_path):
+    """`-din gen:...` is a data source like any file: training on it equals training on the same rows written out."""
+    spec = "gen:k=6,dim=16,n=1500,seed=31"
+    run("datconv", "-din", spec, "-dout", tmp_path / "g.f32")
+    run("randinit", "-din", spec, "-cout", tmp_path / "i.cod", "-xdim", 8, "-ydim", 6, "-topol", "hexa", "-neigh", "bubble", "-rand", 5, "-v", 0)
+    run("vsom", "-din", spec, "-cin", tmp_path / "i.cod", "-cout", tmp_path / "a.cod", "-rlen", 3000, "-alpha", 0.05, "-radius", 4, "-v", 0)
+    run("vsom", "-din", tmp_path / "g.f32", "-cin", tmp_path / "i.cod", "-cout", tmp_path / "b.cod", "-rlen", 3000, "-alpha", 0.05, "-radius", 4, "-v", 0)
+    assert md5(tmp_path / "a.cod") == md5(tmp_path / "b.cod")

@@ -675,3 +675,23 @@ def test_random_parity_sweep_short():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "20", "4242"], cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert p.returncode == 0 and "fuzz ok" in p.stdout, p.stdout[-2000:]
+
+
+def test_device_generator_equals_host_stream(eng, E, oracle):
+    """somhip_dataset_generate (k_gen_mixture) against the host form of the stream (engine.gen_rows, itself pinned to
+    paklib.c's pak_gen_row on the CPU): mixture ids equal, and the winners of the generated rows on a codebook --
+    index and distance bits -- equal those of the host rows uploaded the ordinary way, windows included."""
+    seed, k, dim, n = 20251, 9, 24, 3000
+    hx, hc = E.gen_rows(seed, k, dim, 0, n)
+    dsg = E.Dataset(eng, generate=(seed, k, dim, 0, n))
+    assert np.array_equal(dsg.centres, hc)
+    cb = E.Codebook(eng, hx[::13][:150].copy())
+    gi, gd, _ = E.find_winners(cb, dsg)
+    hi, hd, _ = E.find_winners(cb, E.Dataset(eng, hx))
+    assert np.array_equal(gi, hi) and np.array_equal(bits(gd), bits(hd))
+    wi, wd, _ = oracle.winners(hx[::13][:150].copy(), hx[:400])
+    assert np.array_equal(gi[:400], wi) and np.array_equal(bits(gd[:400]), bits(wd))
+    dsw = E.Dataset(eng, generate=(seed, k, dim, 1234, 500))               # a window of the same stream
+    assert np.array_equal(dsw.centres, hc[1234:1734])
+    wi2, wd2, _ = E.find_winners(cb, dsw)
+    assert np.array_equal(wi2, hi[1234:1734]) and np.array_equal(bits(wd2), bits(hd[1234:1734]))
