@@ -49,7 +49,11 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
                                                      const StepScalars *__restrict__ sc,
                                                      uint32_t *__restrict__ cnt,
                                                      MemberEntry *__restrict__ ent,
-                                                     unsigned long long *__restrict__ stats) {
+                                                     unsigned long long *__restrict__ stats,
+                                                     int64_t xoff_first = -1, int64_t xoff_rows = 0) {
+  // xoff_first >= 0 (the consumer is K4s): the entry carries, instead of the sample's index in the run, where its
+  // row starts in the data array in float4 units -- ((xoff_first + index) mod xoff_rows) * d / 4 -- so that the
+  // update kernel's scalar unit adds instead of wrapping and multiplying per entry
   constexpr int RR = 4;                 // samples per thread and trip: their loads are issued together
   constexpr int NW = NT / 64;
   static_assert(RR * NW <= 64, "the (round, wave) counts are scanned by one wavefront");
@@ -179,7 +183,10 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
       const unsigned long long m = mm[r];
       if (m != 0) {
         MemberEntry e;
-        e.sample = static_cast<uint32_t>(b0 + NT * r + tid); e.alpha = al[r]; e.mask = m;
+        const int64_t bidx = b0 + NT * r + tid;
+        e.sample = xoff_first < 0 ? static_cast<uint32_t>(bidx)
+                                  : static_cast<uint32_t>(((xoff_first + bidx) % xoff_rows) * (cb.d >> 2));
+        e.alpha = al[r]; e.mask = m;
         out[base + s_wcount[r * NW + wave] + __popcll(bal[r] & ((1ull << lane) - 1))] = e;
         rows_total += __popcll(m);
         pairs_total += 1;
@@ -484,11 +491,9 @@ __global__ __launch_bounds__(256) void k_som_update_bubble_s(CbView cb, const fl
   const MemberEntry *list = ent + g * count;
   const float *xbase = rows + 4 * q0;
   const uint32_t last = n_ent - 1u;
-  const uint32_t nr = static_cast<uint32_t>(n_rows), df = static_cast<uint32_t>(data_first);   // host: n_rows < 2^31
+  // the entry's first word is the row's start in float4 units (K4b's xoff mode; host: n_rows * d / 4 < 2^32)
   auto xrow = [&](const u32x4_t &e) -> const float * {
-    uint32_t r = df + e.x;                             // host: count <= n_rows, so one wrap at most
-    if (r >= nr) r -= nr;
-    return xbase + static_cast<int64_t>(r) * cb.d;
+    return xbase + (static_cast<uint64_t>(e.x) << 2);
   };
   auto entry = [&](uint32_t k) -> const MemberEntry * {      // clamped: past the end the last entry is re-read, never applied
     return list + __builtin_amdgcn_readfirstlane(static_cast<int>(k < last ? k : last));
