@@ -112,32 +112,36 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
           const bool rect = cb.topol == 4;
           const int K = static_cast<int>(floor(static_cast<double>(s.thresh) * (rect ? 1.0 : 4.0)));
           if (K >= 0) {
+            // branch-free per lattice row: W = floor(sqrt(rem)) from the hardware's 1-ulp sqrt, corrected by
+            // integer comparisons (rem < 2^24: exact in fp32); ceil / floor of the halves by arithmetic shifts;
+            // the row's run of members as 8 bits of one of two 32-bit words
+            const int c3 = rect ? 1 : 3;
+            uint32_t mw0 = 0, mw1 = 0;
 #pragma unroll
             for (int iy = 0; iy < 8; iy++) {
-              const int ty = g_ty0 + iy, dy = w.y - ty;
-              const int rem = K - (rect ? dy * dy : 3 * dy * dy);
-              if (rem < 0) continue;
-              int W = static_cast<int>(sqrtf(static_cast<float>(rem)));      // integer sqrt, corrected
-              while ((W + 1) * (W + 1) <= rem) W++;
-              while (W * W > rem) W--;
+              const int dy = w.y - (g_ty0 + iy);
+              const int rem = K - c3 * dy * dy;
+              int W = static_cast<int>(__builtin_amdgcn_sqrtf(static_cast<float>(rem < 0 ? 0 : rem)));
+              W += ((W + 1) * (W + 1) <= rem);
+              W += ((W + 1) * (W + 1) <= rem);
+              W -= (W * W > rem);
+              W -= (W * W > rem);
               // rect: |bx - tx| <= W.  hexa: |2(bx - tx) + o| <= W, o = 0 on same-parity rows,
-              // -1 when by is even, +1 when by is odd (som_rout.c:440-447)
+              // -1 when by is even, +1 when by is odd (som_rout.c:440-447):  2 bx + o - W <= 2 tx <= 2 bx + o + W
               int lo, hi;
               if (rect) { lo = w.x - W; hi = w.x + W; }
               else {
-                const int o = (dy & 1) ? ((w.y & 1) ? 1 : -1) : 0;
-                // 2 bx + o - W <= 2 tx <= 2 bx + o + W
-                const int a = 2 * w.x + o - W, b = 2 * w.x + o + W;
-                lo = (a + (a >= 0 ? 1 : 0)) / 2; if (2 * lo < a) lo++;      // ceil(a / 2)
-                hi = b >= 0 ? b / 2 : -((-b + 1) / 2);                       // floor(b / 2)
+                const int cx = 2 * w.x + ((dy & 1) ? ((w.y & 1) ? 1 : -1) : 0);
+                lo = (cx - W + 1) >> 1;                    // ceil((cx - W) / 2)
+                hi = (cx + W) >> 1;                        // floor((cx + W) / 2)
               }
-              lo = lo < g_tx0 ? g_tx0 : lo;
-              hi = hi > g_tx0 + 7 ? g_tx0 + 7 : hi;
-              if (lo <= hi) {
-                const unsigned long long run = ((1ull << (hi - lo + 1)) - 1) << (lo - g_tx0);
-                m |= run << (8 * iy);
-              }
+              lo = (lo < g_tx0 ? g_tx0 : lo) - g_tx0;
+              hi = (hi > g_tx0 + 7 ? g_tx0 + 7 : hi) - g_tx0;
+              const int len = hi - lo + 1;                 // <= 8
+              const uint32_t run = (rem >= 0 && len > 0) ? (((1u << len) - 1u) << lo) : 0u;
+              if (iy < 4) mw0 |= run << (8 * iy); else mw1 |= run << (8 * (iy - 4));
             }
+            m = (static_cast<unsigned long long>(mw1) << 32) | mw0;
           }
         } else if (cb.patch_w) {
           for (int u = 0; u < 64; u++) {                 // maps wider than 1024: per-unit test
