@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 python3 bench.py > $OUT/bench_default_n1.json 2> $OUT/bench_default_n1.err
 tail -c 600 $OUT/bench_default_n1.json; echo
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python3 $ROOT/bench.py --steps 32 --warmup 4 --cpu-vectors 0 --online-vectors 0 > $OUT/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python3 $ROOT/bench.py --cpu-vectors 0 --online-vectors 0 > $OUT/stats.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o p -- python3 $ROOT/bench.py --steps 4 --warmup 1 --cpu-vectors 0 --online-vectors 0 > $OUT/pmc_$C.log 2>&1
 done

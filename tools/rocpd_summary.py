@@ -3,7 +3,7 @@
 
   python tools/rocpd_summary.py gpurun_out/prof_r01 profiles r01
 
-writes  profiles/<tag>_kernel_stats_bench_steps32.csv   (kernel-trace --stats equivalent)
+writes  profiles/<tag>_kernel_stats_bench_default.csv   (kernel-trace --stats equivalent)
         profiles/<tag>_pmc_traffic.json + _pmc_hbm_traffic.txt   (FETCH_SIZE / WRITE_SIZE passes)
         profiles/<tag>_pmc_sq_counters.txt                       (SQ pass)
 gfx950 corrections (MI355X_MICROARCH.md, HBM / rocprofv3): FETCH_SIZE / WRITE_SIZE are KiB;
@@ -47,7 +47,7 @@ def counters(db):
 
 def main():
     src, dst, tag = sys.argv[1:4]
-    kernel_stats(f"{src}/stats/s_results.db", f"{dst}/{tag}_kernel_stats_bench_steps32.csv")
+    kernel_stats(f"{src}/stats/s_results.db", f"{dst}/{tag}_kernel_stats_bench_default.csv")
     f = counters(f"{src}/pmc_FETCH_SIZE/p_results.db")
     w = counters(f"{src}/pmc_WRITE_SIZE/p_results.db")
     note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), "
