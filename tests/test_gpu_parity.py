@@ -695,3 +695,38 @@ def test_device_generator_equals_host_stream(eng, E, oracle):
     assert np.array_equal(dsw.centres, hc[1234:1734])
     wi2, wd2, _ = E.find_winners(cb, dsw)
     assert np.array_equal(wi2, hi[1234:1734]) and np.array_equal(bits(wd2), bits(hd[1234:1734]))
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 64, 3, 1, 64), (24, 8, 64, 4, 1, 100), (16, 24, 128, 3, 1, 333), (10, 7, 64, 3, 1, 30),
+                                   (16, 16, 64, 3, 2, 64), (8, 24, 16, 4, 2, 37), (13, 9, 32, 3, 2, 50)])
+def test_scalar_operand_update_kernels_vs_oracle(eng, E, oracle, shape, monkeypatch):
+    """The scalar-operand update kernels (k_som_update_bubble_s: scalar loads of member entries and sample
+    slices, exec mask from the entry, packed fp32; k_som_update_gauss_s: rates once per workgroup through LDS)
+    are picked by size on big maps; here they are forced on small ones (SOMHIP_UPD_QW=4) and compared with the
+    batch oracle bit for bit -- data set wrapped, batch not a multiple of the tile, patch and linear row order,
+    and against the LDS-tile kernel (SOMHIP_UPD_LDS=1) on the same run."""
+    xdim, ydim, dim, topol, neigh, batch = shape
+    x, _ = synth(61 + dim, 900, dim)
+    ini = oracle.randinit(x, xdim, ydim, 3)
+    length = 1400                                                   # wraps the data set
+    oc, oi, od = oracle.som_train(ini, xdim, ydim, topol, neigh, x, length, 0.06, 6.0, batch=batch)
+    ds = E.Dataset(eng, x)
+    got = {}
+    for form in ("scalar", "lds"):
+        monkeypatch.setenv("SOMHIP_UPD_QW", "4")
+        if form == "lds":
+            monkeypatch.setenv("SOMHIP_UPD_LDS", "1")
+        cb = E.Codebook(eng, ini, topol, neigh, xdim, ydim)
+        eng.timing(True)
+        eng.timing_reset()
+        ti, td = E.som_train(cb, ds, length, 0.06, 6.0, batch=batch)
+        table = eng.timing_table()
+        eng.timing(False)
+        monkeypatch.delenv("SOMHIP_UPD_LDS", raising=False)
+        assert np.array_equal(ti, oi) and np.array_equal(bits(td), bits(od)), form
+        got[form] = cb.download()
+        assert np.array_equal(bits(got[form]), bits(oc)), form
+        if form == "scalar" and neigh == 1:
+            assert table["k_som_update_bubble_s"][0] > 0               # the kernel under test did run (dim % 64 == 0)
+        if form == "lds":
+            assert table["k_som_update_bubble_s"][0] == 0 and table["k_som_update_run"][0] > 0
