@@ -92,6 +92,40 @@ def unpack_knn_keys(keys):
     return diff, index
 
 
+def gather_codebook(local_rows, units, n_global, group=None):
+    """X3 (save / snapshot): every rank contributes the rows it owns and the global unit index of each
+    (contiguous block: arange(r0, r1); interleaved shard: engine.shard_units) and gets the whole codebook
+    back in the reference's row order (datafile.c:781,836).  Shards may differ in size (padded to the largest
+    for the all-gather).  numpy in, numpy out; the exchange runs on the process group's backend."""
+    import torch
+    import torch.distributed as dist
+    rows = np.ascontiguousarray(local_rows, dtype=np.float32)
+    units = np.ascontiguousarray(units, dtype=np.int64)
+    assert rows.shape[0] == units.shape[0]
+    full = np.empty((n_global, rows.shape[1]), dtype=np.float32)
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        full[units] = rows
+        return full
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    count = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    most = int(max(int(c.item()) for c in counts))
+    pad_rows = torch.zeros((most, rows.shape[1]), dtype=torch.float32, device=dev)
+    pad_units = torch.full((most,), -1, dtype=torch.int64, device=dev)
+    pad_rows[:rows.shape[0]] = torch.from_numpy(rows).to(dev)
+    pad_units[:units.shape[0]] = torch.from_numpy(units).to(dev)
+    all_rows = [torch.empty_like(pad_rows) for _ in range(world)]
+    all_units = [torch.empty_like(pad_units) for _ in range(world)]
+    dist.all_gather(all_rows, pad_rows, group=group)
+    dist.all_gather(all_units, pad_units, group=group)
+    for r, u, c in zip(all_rows, all_units, counts):
+        k = int(c.item())
+        full[u[:k].cpu().numpy()] = r[:k].cpu().numpy()
+    return full
+
+
 class ShardedSom:
     """Mini-batch SOM training over a row-sharded codebook.
 

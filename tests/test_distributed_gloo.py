@@ -90,12 +90,8 @@ def _worker(rank, world, port, q):
             som = sharded.ShardedSom(sh, B, x.shape[0])
             winners = som.train(length)
             widx = np.concatenate([sharded.unpack_keys(w.numpy())[1] for w in winners])
-            gathered = [None] * world
-            dist.all_gather_object(gathered, (units, sh.rows))
+            full = sharded.gather_codebook(sh.rows, units, n)          # X3: uneven shards, both layouts
             if rank == 0:
-                full = np.empty_like(ini)
-                for u, r in gathered:
-                    full[u] = r
                 want, wi, _ = orc.som_train(ini, xdim, ydim, topol, neigh, x, length, 0.09, 3.0, batch=B)
                 out[case] = (bool(np.array_equal(full.view(np.uint32), want.view(np.uint32))),
                              bool(np.array_equal(widx, wi)))
