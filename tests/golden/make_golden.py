@@ -153,7 +153,37 @@ def lvq_tool_goldens(exp, d):
     exp["lvq"]["tools"] = t
 
 
+def c2_full_golden(exp):
+    """BASELINE.json configs[1] at full size through the REAL reference: 100 000 vectors x 128 of the seeded
+    generator stream (engine.gen_rows == paklib.c pak_gen_row == k_gen_mixture), written as text with %.9g (exact
+    round trip through sscanf("%f")), randinit 32x32 hexa bubble -rand 7, vsom -rlen 100000 -alpha 0.05 -radius 10,
+    qerror.  Only hashes and stdout are kept; the GPU test regenerates the data from the same spec."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from som_lvq_pak_amd import engine as E
+    spec = {"k": 16, "dim": 128, "n": 100000, "seed": 1234}
+    x, _ = E.gen_rows(spec["seed"], spec["k"], spec["dim"], 0, spec["n"])
+    with tempfile.TemporaryDirectory() as td:
+        dat = os.path.join(td, "c2.dat")
+        with open(dat, "w") as f:
+            f.write("%d\n" % spec["dim"])
+            for row in x:
+                f.write(" ".join("%.9g" % v for v in row) + "\n")
+        init, out = os.path.join(td, "init.cod"), os.path.join(td, "out.cod")
+        run("randinit", "-din", dat, "-cout", init, "-xdim", 32, "-ydim", 32, "-topol", "hexa", "-neigh", "bubble", "-rand", 7)
+        run("vsom", "-din", dat, "-cin", init, "-cout", out, "-rlen", 100000, "-alpha", 0.05, "-radius", 10)
+        exp["c2_full"] = {"gen": "gen:k=%(k)d,dim=%(dim)d,n=%(n)d,seed=%(seed)d" % spec, "xdim": 32, "ydim": 32, "rand": 7,
+                          "rlen": 100000, "alpha": 0.05, "radius": 10, "init_md5": md5(init), "md5": md5(out),
+                          "qerror_stdout": run("qerror", "-din", dat, "-cin", out)}
+
+
 def main():
+    if "--c2" in sys.argv:                 # refresh only that section of expected.json
+        build()
+        exp = json.load(open(os.path.join(CLI, "expected.json")))
+        c2_full_golden(exp)
+        json.dump(exp, open(os.path.join(CLI, "expected.json"), "w"), indent=1, sort_keys=True)
+        return
     if "--lvq-tools" in sys.argv:          # refresh only that section of expected.json
         build()
         exp = json.load(open(os.path.join(CLI, "expected.json")))
@@ -234,6 +264,7 @@ def main():
     vfind_golden(exp, d)
     lininit_golden(exp, d)
     buffer_golden(exp, d)
+    c2_full_golden(exp)
     json.dump(exp, open(os.path.join(CLI, "expected.json"), "w"), indent=1, sort_keys=True)
 
     # ---------------- in-memory traces through the harness ----------------

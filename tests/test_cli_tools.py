@@ -388,3 +388,20 @@ def test_vsom_on_generated_source(tools, tmp_path):
     run("vsom", "-din", spec, "-cin", tmp_path / "i.cod", "-cout", tmp_path / "a.cod", "-rlen", 3000, "-alpha", 0.05, "-radius", 4, "-v", 0)
     run("vsom", "-din", tmp_path / "g.f32", "-cin", tmp_path / "i.cod", "-cout", tmp_path / "b.cod", "-rlen", 3000, "-alpha", 0.05, "-radius", 4, "-v", 0)
     assert md5(tmp_path / "a.cod") == md5(tmp_path / "b.cod")
+
+
+@pytest.mark.gpu
+def test_c2_full_size_matches_reference_cli(tools, tmp_path):
+    """BASELINE.json configs[1] at FULL size (32x32 hexa bubble map, 100 000 vectors x 128, -rlen 100000): the
+    REAL reference trained on the text form of the generator stream (tests/golden/make_golden.py c2_full_golden);
+    here randinit / vsom / qerror read the same stream from `-din gen:...` and must give the reference's bytes --
+    100 000 online iterations on the GPU, bit-exact."""
+    ex = EXPECTED["c2_full"]
+    init, out = tmp_path / "init.cod", tmp_path / "out.cod"
+    run("randinit", "-din", ex["gen"], "-cout", init, "-xdim", ex["xdim"], "-ydim", ex["ydim"], "-topol", "hexa",
+        "-neigh", "bubble", "-rand", ex["rand"], "-v", 0)
+    assert md5(init) == ex["init_md5"]
+    run("vsom", "-din", ex["gen"], "-cin", init, "-cout", out, "-rlen", ex["rlen"], "-alpha", ex["alpha"],
+        "-radius", ex["radius"], "-v", 0)
+    assert md5(out) == ex["md5"]
+    assert run("qerror", "-din", ex["gen"], "-cin", out, "-v", 0).stdout == ex["qerror_stdout"]
