@@ -405,3 +405,24 @@ def test_c2_full_size_matches_reference_cli(tools, tmp_path):
         "-radius", ex["radius"], "-v", 0)
     assert md5(out) == ex["md5"]
     assert run("qerror", "-din", ex["gen"], "-cin", out, "-v", 0).stdout == ex["qerror_stdout"]
+
+
+def test_raw_fp32_reader_rejects_truncated_files(tools, tmp_path):
+    """a payload or a text section shorter than the header promises is an error message and exit 1, not a crash
+    (the reader runs clean under -fsanitize=address,undefined on these inputs as well)"""
+    import struct
+    short = tmp_path / "short.f32"
+    short.write_bytes(b"#!somf32 5 0\n3\n" + struct.pack("<6f", *range(6)))
+    p = run("datconv", "-din", short, "-dout", tmp_path / "o.f32", check=False)
+    assert p.returncode == 1 and "shorter than its header says" in p.stderr
+    text = tmp_path / "text.f32"
+    text.write_bytes(b"#!somf32 2 1\n2\n" + struct.pack("<4f", 1, 2, 3, 4) + b"lab1\n")
+    p = run("datconv", "-din", text, "-dout", tmp_path / "o.f32", check=False)
+    assert p.returncode == 1 and "text section ends at row 1" in p.stderr
+    ok = tmp_path / "ok.f32"
+    ok.write_bytes(b"#!somf32 2 1\n2\n" + struct.pack("<4f", 1, 2, float("nan"), 4) + b"a\nb weight=3\n")
+    run("datconv", "-din", ok, "-dout", tmp_path / "ok.txt", "-text")
+    # (the text writer prints numbers and labels only, as the reference's write_entry does, datafile.c:420-447)
+    assert open(tmp_path / "ok.txt").read().split("\n")[:3] == ["2", "1 2 a ", "x 4 b "]
+    run("datconv", "-din", ok, "-dout", tmp_path / "ok2.f32")
+    assert open(tmp_path / "ok2.f32", "rb").read().endswith(b"a \nb weight=3 \n")
