@@ -292,7 +292,9 @@ static struct entries *read_f32(FILE *fp, const char *first_line, const char *na
   struct fixpoint *fixtmp = NULL;
   char **maskrows = NULL;
   int any_fixed = 0, any_weight = 0, dim;
-  if (getline(&line, &cap, fp) < 0 || !(dim = parse_header(e, line, name))) goto fail;
+  if (getline(&line, &cap, fp) < 0) goto fail;
+  { size_t L = strlen(line); while (L && (line[L - 1] == '\n' || line[L - 1] == '\r')) line[--L] = 0; }
+  if (!(dim = parse_header(e, line, name))) goto fail;
   e->points = malloc(sizeof(float) * (size_t)(n ? n : 1) * dim);
   e->rows = calloc((size_t)(n ? n : 1), sizeof(struct data_entry));
   if (fread(e->points, sizeof(float) * dim, (size_t)n, fp) != (size_t)n) { fprintf(stderr, "file %s is shorter than its header says\n", name); goto fail; }
@@ -553,6 +555,9 @@ static void write_rows(FILE *fp, struct entries *c, const char *comments)
 int save_entries_wcomments(struct entries *codes, const char *name, const char *comments)
 {
   int is_pipe;
+  size_t nl = strlen(name);
+  if (nl > 4 && strcmp(name + nl - 4, ".f32") == 0)      /* a name ending in .f32 asks for the raw fp32 side format */
+    return save_entries_f32(codes, name);                /* (a 256x256x512 codebook is 400 MB of "%g" text otherwise)  */
   FILE *fp = open_text(name, "w", &is_pipe);
   if (!fp) { fprintf(stderr, "save_entries: Can't open file '%s'\n", name); return 1; }
   write_rows(fp, codes, comments);

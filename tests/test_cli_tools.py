@@ -337,6 +337,12 @@ def test_datconv_raw_fp32_roundtrip(tools, tmp_path):
         assert md5(tmp_path / "a.f32") == md5(tmp_path / "b.f32"), name          # raw -> raw is the identity
     xm, tailm = _f32_payload(tmp_path / "a.f32")
     assert len(tailm.splitlines()) == xm.shape[0]                    # ex1.dat: one label line per row
+    # a map file keeps its header (topology, size, neighbourhood); a -cout name ending in .f32 selects the raw format
+    run("randinit", "-din", ex, "-cout", tmp_path / "i.f32", "-xdim", 12, "-ydim", 8, "-topol", "hexa", "-neigh", "bubble", "-rand", 5, "-v", 0)
+    run("randinit", "-din", ex, "-cout", tmp_path / "i.cod", "-xdim", 12, "-ydim", 8, "-topol", "hexa", "-neigh", "bubble", "-rand", 5, "-v", 0)
+    run("datconv", "-din", tmp_path / "i.f32", "-dout", tmp_path / "i.txt", "-text")
+    want_lines = [ln for ln in open(tmp_path / "i.cod").read().split("\n") if not ln.startswith("#")]
+    assert open(tmp_path / "i.txt").read().split("\n") == want_lines and want_lines[0] == "5 hexa 12 8 bubble"
 
 
 def test_generator_source_equals_its_restatement(tools, tmp_path):
