@@ -50,7 +50,8 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
                                                      uint32_t *__restrict__ cnt,
                                                      MemberEntry *__restrict__ ent,
                                                      unsigned long long *__restrict__ stats,
-                                                     int64_t xoff_first = -1, int64_t xoff_rows = 0) {
+                                                     int64_t xoff_first = -1, int64_t xoff_rows = 0,
+                                                     int xoff_scale = 0) {
   // xoff_first >= 0 (the consumer is K4s): the entry carries, instead of the sample's index in the run, where its
   // row starts in the data array in float4 units -- ((xoff_first + index) mod xoff_rows) * d / 4 -- so that the
   // update kernel's scalar unit adds instead of wrapping and multiplying per entry
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
         MemberEntry e;
         const int64_t bidx = b0 + NT * r + tid;
         e.sample = xoff_first < 0 ? static_cast<uint32_t>(bidx)
-                                  : static_cast<uint32_t>(((xoff_first + bidx) % xoff_rows) * (cb.d >> 2));
+                                  : static_cast<uint32_t>(((xoff_first + bidx) % xoff_rows) * xoff_scale);   // scale: d/4 (float4 units) or 4 d (bytes)
         e.alpha = al[r]; e.mask = m;
         out[base + s_wcount[r * NW + wave] + __popcll(bal[r] & ((1ull << lane) - 1))] = e;
         rows_total += __popcll(m);
@@ -440,12 +441,14 @@ template <int NF> struct K4sX;
 template <> struct K4sX<8> {
   f32x8_t v;
   __device__ __forceinline__ void load(const float *p) { asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(v) : "s"(p)); }
+  __device__ __forceinline__ void load_off(const float *base, uint32_t off) { asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(base), "s"(off)); }
   __device__ __forceinline__ void wait(u32x4_t &e) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+s"(e)); }
   __device__ __forceinline__ float4 chunk(int j) const { return make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]); }
 };
 template <> struct K4sX<16> {
   f32x16_t v;
   __device__ __forceinline__ void load(const float *p) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p)); }
+  __device__ __forceinline__ void load_off(const float *base, uint32_t off) { asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(base), "s"(off)); }
   __device__ __forceinline__ void wait(u32x4_t &e) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+s"(e)); }
   // (the VGPR operand goes through its own, empty statement: an asm with a vector output makes all its outputs divergent)
   __device__ __forceinline__ void wait(u32x4_t &e, float &a) { wait(e); asm volatile("" : "+v"(a)); }
@@ -466,8 +469,15 @@ template <> struct K4sX<32> {
 __device__ __forceinline__ void k4s_load_entry(u32x4_t &e, const MemberEntry *p) {
   asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(e) : "s"(p));
 }
+__device__ __forceinline__ void k4s_load_entry_off(u32x4_t &e, const MemberEntry *base, uint32_t off) {
+  asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(e) : "s"(base), "s"(off));
+}
 
-template <int QW, bool PK = false>
+// OFF32 (data set smaller than 4 GiB): the entries carry the BYTE offset of the sample's row and both kinds of
+// scalar load take their address as base + register offset, so an entry costs the scalar unit three instructions
+// of address work instead of ten (8 scalar instructions per entry in all; the measured time did not change --
+// neither on the whole map, where the vector ALU is the bound, nor on an eighth of it).
+template <int QW, bool PK = false, bool OFF32 = false>
 __global__ __launch_bounds__(256) void k_som_update_bubble_s(CbView cb, const float *__restrict__ rows,
                                                              int64_t n_rows, int64_t data_first, int64_t count,
                                                              const uint32_t *__restrict__ cnt,
@@ -528,6 +538,29 @@ __global__ __launch_bounds__(256) void k_som_update_bubble_s(CbView cb, const fl
   // about that window (tests/test_build.py checks the ISA for it).
   u32x4_t e0, e1, e2, e3;
   K4sX<4 * QW> xA, xB;
+  if constexpr (OFF32) {
+    const uint32_t lastoff = last * 16u;
+    uint32_t ko = lastoff < 32u ? lastoff : 32u;          // byte offset of the entry loaded next (clamped like entry())
+    k4s_load_entry(e0, list);
+    k4s_load_entry_off(e1, list, lastoff < 16u ? lastoff : 16u);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e0), "+s"(e1));
+    xA.load_off(xbase, e0.x);
+    k4s_load_entry_off(e2, list, ko);
+#define K4S_PHASE(XC, XN, EK, EK1, EK2, EK3)        \
+    XC.wait(EK2);                                     \
+    XN.load_off(xbase, EK1.x);                        \
+    ko = ko + 16u < lastoff ? ko + 16u : lastoff;     \
+    k4s_load_entry_off(EK3, list, ko);                \
+    apply(EK, XC);                                    \
+    if (++k >= n_ent) break;
+    for (uint32_t k = 0;;) {
+      K4S_PHASE(xA, xB, e0, e1, e2, e3)
+      K4S_PHASE(xB, xA, e1, e2, e3, e0)
+      K4S_PHASE(xA, xB, e2, e3, e0, e1)
+      K4S_PHASE(xB, xA, e3, e0, e1, e2)
+    }
+#undef K4S_PHASE
+  } else {
   k4s_load_entry(e0, entry(0));
   k4s_load_entry(e1, entry(1));
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e0), "+s"(e1));
@@ -546,6 +579,7 @@ __global__ __launch_bounds__(256) void k_som_update_bubble_s(CbView cb, const fl
     K4S_PHASE(xB, xA, e3, e0, e1, e2)
   }
 #undef K4S_PHASE
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing of ours may still be landing in SGPRs at exit
 #pragma unroll
   for (int j = 0; j < QW; j++) *tile_ptr_w(cb, g, q0 + j, lane) = c[j];
