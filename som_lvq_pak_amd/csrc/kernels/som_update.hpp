@@ -41,6 +41,10 @@ __global__ void k_decode_winners(const uint64_t *__restrict__ keys, const StepSc
 //   ent[g*count + k]       {sample index in the run, member mask}
 // =====================================================================================
 struct MemberEntry { uint32_t sample; float alpha; unsigned long long mask; };   // alpha: the iteration's rate
+// a group's list has room for every sample of the run plus LIST_PAD null entries (mask 0, offset 0) that K4b writes
+// behind the real ones: K4s walks the list four entries at a time and prefetches three ahead without a bound check
+constexpr int LIST_PAD = 8;
+__host__ __device__ __forceinline__ int64_t list_stride(int64_t count) { return count + LIST_PAD; }
 
 template <bool GAUSS, int NT>          // NT threads: 256, or 1024 when a small shard has few row groups to spread
 __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
   const int g_txa = cb.patch_w ? g_tx0 : (g_ty0 == g_ty1 ? g_tx0 : 0);
   const bool small_map = cb.xdim <= 1024 && g_ty1 < 1024;
   const unsigned long long live_mask = nlive >= 64 ? ~0ull : ((1ull << nlive) - 1);
-  MemberEntry *out = ent + g * count;
+  MemberEntry *out = ent + g * list_stride(count);
   uint32_t base = 0;
   unsigned long long rows_total = 0, pairs_total = 0;
 
@@ -201,6 +205,7 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
     __syncthreads();
   }
   if (tid == 0) cnt[g] = base;
+  if (tid < LIST_PAD) { MemberEntry z; z.sample = 0u; z.alpha = 0.0f; z.mask = 0ull; out[base + tid] = z; }
   // instrumentation: (row, iteration) updates and (row group, iteration) pairs of this run
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256) void k_som_update_run(CbView cb, const float *
   const int qblk = static_cast<int>(item % nslices) * BQ;
   const int q0 = qblk + wave * QW;
   const bool vec = (cb.d & 3) == 0;
-  const MemberEntry *list = ent + g * count;
+  const MemberEntry *list = ent + g * list_stride(count);
   int tx, ty;
   txty_of_row(cb, g * WAVE + lane, tx, ty);
 
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(256) void k_som_update_bubble_s(CbView cb, const fl
 #pragma unroll
   for (int j = 0; j < QW; j++) c[j] = *tile_ptr(cb, g, q0 + j, lane);
 
-  const MemberEntry *list = ent + g * count;
+  const MemberEntry *list = ent + g * list_stride(count);
   const float *xbase = rows + 4 * q0;
   const uint32_t last = n_ent - 1u;
   // the entry's first word is the row's start in float4 units (K4b's xoff mode; host: n_rows * d / 4 < 2^32)
@@ -539,21 +544,20 @@ __global__ __launch_bounds__(256) void k_som_update_bubble_s(CbView cb, const fl
   u32x4_t e0, e1, e2, e3;
   K4sX<4 * QW> xA, xB;
   if constexpr (OFF32) {
-    const uint32_t lastoff = last * 16u;
-    uint32_t ko = lastoff < 32u ? lastoff : 32u;          // byte offset of the entry loaded next (clamped like entry())
+    // the list is followed by LIST_PAD null entries: no clamping of the prefetches, one exit test per four entries
+    uint32_t ko = 32u;                                    // byte offset of the entry loaded next
     k4s_load_entry(e0, list);
-    k4s_load_entry_off(e1, list, lastoff < 16u ? lastoff : 16u);
+    k4s_load_entry_off(e1, list, 16u);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e0), "+s"(e1));
     xA.load_off(xbase, e0.x);
     k4s_load_entry_off(e2, list, ko);
 #define K4S_PHASE(XC, XN, EK, EK1, EK2, EK3)        \
     XC.wait(EK2);                                     \
     XN.load_off(xbase, EK1.x);                        \
-    ko = ko + 16u < lastoff ? ko + 16u : lastoff;     \
+    ko += 16u;                                        \
     k4s_load_entry_off(EK3, list, ko);                \
-    apply(EK, XC);                                    \
-    if (++k >= n_ent) break;
-    for (uint32_t k = 0;;) {
+    apply(EK, XC);
+    for (uint32_t k = 0; k < n_ent; k += 4u) {
       K4S_PHASE(xA, xB, e0, e1, e2, e3)
       K4S_PHASE(xB, xA, e1, e2, e3, e0)
       K4S_PHASE(xA, xB, e2, e3, e0, e1)
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(1024) void k_som_update_gauss_s(CbView cb, const fl
 #pragma unroll
   for (int j = 0; j < QW; j++) c[j] = *tile_ptr(cb, g, q0 + j, lane);
 
-  const MemberEntry *list = ent + g * count;
+  const MemberEntry *list = ent + g * list_stride(count);
   const float *xbase = rows + 4 * q0;
   const uint32_t last = n_ent - 1u;
   const uint32_t nr = static_cast<uint32_t>(n_rows), df = static_cast<uint32_t>(data_first);
