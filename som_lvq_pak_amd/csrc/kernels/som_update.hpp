@@ -506,6 +506,8 @@ __global__ __launch_bounds__(256) void k_som_update_bubble_s(CbView cb, const fl
   float4 c[QW];
 #pragma unroll
   for (int j = 0; j < QW; j++) c[j] = *tile_ptr(cb, g, q0 + j, lane);
+  // (waited for here, once: otherwise the compiler keeps one s_waitcnt vmcnt per chunk inside every phase of the loop)
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
 
   const MemberEntry *list = ent + g * list_stride(count);
   const float *xbase = rows + 4 * q0;
@@ -631,6 +633,8 @@ __global__ __launch_bounds__(1024) void k_som_update_gauss_s(CbView cb, const fl
   float4 c[QW];
 #pragma unroll
   for (int j = 0; j < QW; j++) c[j] = *tile_ptr(cb, g, q0 + j, lane);
+  // (waited for here, once: otherwise the compiler keeps one s_waitcnt vmcnt per chunk inside every phase of the loop)
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
 
   const MemberEntry *list = ent + g * list_stride(count);
   const float *xbase = rows + 4 * q0;
