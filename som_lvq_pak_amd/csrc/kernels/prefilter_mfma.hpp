@@ -58,6 +58,7 @@ struct RerankInit {
   uint32_t *pair_count;  // overflow word
   int64_t bpad;
   int ncols;
+  uint64_t key_init;     // KEY_NONE, or INT64_MAX when the keys go straight into a signed MIN all-reduce
 };
 __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int d, int64_t first,
                              int64_t count, const unsigned int *__restrict__ cn_max_bits,
@@ -66,7 +67,7 @@ __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int
   const int lane = threadIdx.x & 63;
   if (init.gmin) {                                       // 64 * count threads >= bpad + 4 * ncols
     const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (t < count && init.keys) init.keys[t] = KEY_NONE;
+    if (t < count && init.keys) init.keys[t] = init.key_init;
     if (t < init.bpad) { init.gmin[t] = 0xFFFFFFFFu; init.gmin[init.bpad + t] = 0u; }
     if (t < 4 * static_cast<int64_t>(init.ncols)) init.gmin[2 * init.bpad + t] = 0u;
     if (t == 0) *init.pair_count = 0u;
