@@ -730,3 +730,25 @@ def test_scalar_operand_update_kernels_vs_oracle(eng, E, oracle, shape, monkeypa
             assert table["k_som_update_bubble_s"][0] > 0               # the kernel under test did run (dim % 64 == 0)
         if form == "lds":
             assert table["k_som_update_bubble_s"][0] == 0 and table["k_som_update_run"][0] > 0
+
+
+@pytest.mark.parametrize("batch", [64, 61, 4])
+def test_scalar_update_kernel_full_lists(eng, E, oracle, batch, monkeypatch):
+    """Radius larger than the map: every sample is in every row group's member list, so the lists use their whole
+    capacity and the eight null entries behind them sit at the very end of each group's segment (the scalar-operand
+    kernel prefetches three entries past the last real one and walks four per trip: batch sizes 4k, 4k+1, tiny)."""
+    monkeypatch.setenv("SOMHIP_UPD_QW", "4")
+    xdim, ydim, dim = 16, 16, 64
+    x, _ = synth(97, 500, dim)
+    ini = oracle.randinit(x, xdim, ydim, 11)
+    length = 61 * 12
+    oc, oi, od = oracle.som_train(ini, xdim, ydim, 3, 1, x, length, 0.04, 60.0, batch=batch)
+    cb, ds = E.Codebook(eng, ini, 3, 1, xdim, ydim), E.Dataset(eng, x)
+    eng.timing(True)
+    eng.timing_reset()
+    ti, td = E.som_train(cb, ds, length, 0.04, 60.0, batch=batch)
+    ran = eng.timing_table()["k_som_update_bubble_s"][0]
+    eng.timing(False)
+    assert ran > 0
+    assert np.array_equal(ti, oi) and np.array_equal(bits(td), bits(od))
+    assert np.array_equal(bits(cb.download()), bits(oc))
