@@ -428,11 +428,17 @@ static struct entries *gen_entries(const char *spec)
   e->num_entries = n;
   e->points = malloc(sizeof(float) * (size_t)n * dim);
   e->rows = calloc((size_t)n, sizeof(struct data_entry));
-  for (long r = 0; r < n; r++) {
-    int c;
-    pak_gen_row(seed, k, dim, r, e->points + r * dim, &c);
-    if (labels) { char nm[32]; snprintf(nm, sizeof nm, "c%d", c); add_entry_label(e, r, find_conv_to_ind(nm)); }
+  int *centre = malloc(sizeof(int) * (size_t)n);
+  /* counter-based: every row is independent, so the rows are made in parallel (the label table is not thread-safe:
+   * labels are attached afterwards, in row order, which is also the order the text reader would meet them in) */
+#pragma omp parallel for schedule(static)
+  for (long r = 0; r < n; r++) pak_gen_row(seed, k, dim, r, e->points + r * dim, &centre[r]);
+  for (long r = 0; labels && r < n; r++) {
+    char nm[32];
+    snprintf(nm, sizeof nm, "c%d", centre[r]);
+    add_entry_label(e, r, find_conv_to_ind(nm));
   }
+  free(centre);
   finish_entries(e, NULL, NULL, 0, 0);
   return e;
 }
