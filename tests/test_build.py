@@ -161,6 +161,9 @@ def test_scalar_update_kernel_reads_nothing_before_its_wait(built, tmp_path):
         if "bubble" in name:                               # (the gaussian rate's fp64 exp/sqrt expansions legitimately use fma)
             assert not re.findall(r"\bv_(?:pk_)?(?:fma|fmac|mac|mad)_f32\b.*", body), name
         assert re.search(r"v_(pk_)?mul_f32", body) and re.search(r"v_(pk_)?add_f32", body), name
+        # no scalar-register spills at all: a spill may copy the destination of a load that is still in flight (a
+        # 32-dims-per-wave gaussian variant did exactly that) and the per-block scan below would miss one in another block
+        assert "v_writelane_b32" not in body and "v_readlane_b32" not in body, name
         check(name, body, False)
         # phase structure: every x load (s_load_dwordx16 from the inline assembly) is issued after a wait in its own block
         for blk in re.split(r"\n\.LBB\w+:", body):
