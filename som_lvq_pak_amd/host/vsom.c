@@ -9,7 +9,8 @@ static const char *usage =
     "vsom - teach self-organizing map (MI355X engine)\n"
     "Required:  -cin file  -din file  -cout file  -rlen N  -alpha A  -radius R\n"
     "Optional:  -rand seed  -fixed  -weights  -buffer N  -alpha_type linear|inverse_t\n"
-    "           -snapfile name  -snapinterval N  -selfuncs hip  -batch B  -v level\n";
+    "           -snapfile name  -snapinterval N  -selfuncs hip  -batch B  -v level\n"
+    "Files:     text (.dat/.cod), raw fp32 (a name ending in .f32; see datconv), or -din gen:k=..,dim=..,n=..,seed=..\n";
 
 int main(int argc, char **argv)
 {
