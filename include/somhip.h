@@ -4,9 +4,10 @@
  * (hynde/som_lvq_pak): best-matching-unit search + codebook update inside the
  * vsom / lvqtrain epoch loops, and the read-only winner scans of qerror /
  * accuracy / vcal.  Plain C: opaque handles, plain pointers and sizes, int status
- * (0 = ok, nonzero = error; text via somhip_last_error()).  Nothing here aborts; a
- * failing call leaves a message and returns nonzero, the way the reference's
- * training functions return NULL and print to stderr (som_rout.c:576-596).
+ * (0 = ok, nonzero = error; text via somhip_last_error()).  Nothing here aborts and no
+ * C++ exception crosses this boundary; a failing call leaves a message and returns
+ * nonzero, the way the reference's training functions return NULL and print to stderr
+ * (som_rout.c:576-596).
  *
  * One host thread per engine (the reference is single-threaded and not re-entrant,
  * SURVEY.md 8b); one engine per process per GPU.
@@ -44,7 +45,10 @@ int somhip_version(void);
 
 /* ---- engine ---- */
 int  somhip_engine_create(int device, somhip_engine **out);
-void somhip_engine_destroy(somhip_engine *e);      /* destroy its codebooks / datasets first */
+/* Destroying an engine releases the device memory of every codebook / data set created on it; those handles
+ * stay valid for their own destroy call (any order of the destroy calls is fine), every other call on them
+ * fails with "the engine of this handle was destroyed". */
+void somhip_engine_destroy(somhip_engine *e);
 /* the HIP stream all work of this engine is enqueued on (a hipStream_t) */
 void *somhip_engine_stream(somhip_engine *e);
 int  somhip_engine_sync(somhip_engine *e);
@@ -187,6 +191,12 @@ int  somhip_lvq_stats(somhip_engine *e, uint64_t out[8]);
  * elements with j < i are left 0.  The eigenvector iteration itself is O(dim^2) host work. */
 int  somhip_column_sums(somhip_dataset *ds, float *sum, int64_t *count);
 int  somhip_centered_products(somhip_dataset *ds, const float *mean, float *r);
+
+/* ---- randinit's data pass (randinit_codes, som_rout.c:98-131) --------------------
+ * lo[i] / hi[i] / count[i]: smallest and largest unmasked value of component i over all rows, and their
+ * number (count may be NULL).  The reference seeds its maximum with FLT_MIN and its minimum with FLT_MAX
+ * (:108-111) -- apply that on the result; a component without data returns lo = FLT_MAX, hi = -FLT_MAX. */
+int  somhip_column_minmax(somhip_dataset *ds, float *lo, float *hi, int64_t *count);
 
 /* ---- find_qerror2 (som_rout.c:823-885; bubble_qerror :734-772, gaussian_qerror :775-818):
  * out[i] = sum over the neighbourhood of sample first+i's winner of (h *) d*d, d =

@@ -43,6 +43,7 @@ SIGNATURES = {
     "somhip_scan_stats": (C.c_int, [C.c_void_p, c_u64_p]),
     "somhip_lvq_stats": (C.c_int, [C.c_void_p, c_u64_p]),
     "somhip_column_sums": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(C.c_int64)]),
+    "somhip_column_minmax": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.POINTER(C.c_int64)]),
     "somhip_centered_products": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
     "somhip_qerror2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int64, c_float_p, c_i32_p]),
     "somhip_debug_prefilter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, c_float_p, c_float_p, c_i64_p]),

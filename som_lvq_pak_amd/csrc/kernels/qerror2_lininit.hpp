@@ -153,6 +153,37 @@ __global__ __launch_bounds__(256) void k_centered_products(const float *__restri
   if (i < d && j < d && j >= i) R[static_cast<int64_t>(i) * d + j] = acc;
 }
 
+// K8c: bounding box of the data (randinit_codes, som_rout.c:98-131): per component the smallest and largest
+// unmasked value and how many there are.  min/max are order-independent, so rows are split over the grid and
+// folded with integer atomics on an order-preserving image of the float (sign-magnitude -> biased unsigned).
+__device__ __forceinline__ uint32_t f32_ordered(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ __launch_bounds__(256) void k_column_minmax(const float *__restrict__ rows, const uint8_t *__restrict__ mask,
+                                                       int64_t n, int d, int64_t rows_per_block,
+                                                       uint32_t *__restrict__ omin, uint32_t *__restrict__ omax,
+                                                       unsigned long long *__restrict__ cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d) return;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+  unsigned long long k = 0;
+  for (int64_t r = r0; r < r1; r++) {
+    if (mask && mask[r * d + i]) continue;
+    const uint32_t o = f32_ordered(rows[r * d + i]);
+    lo = o < lo ? o : lo;
+    hi = o > hi ? o : hi;
+    k++;
+  }
+  if (k) {
+    atomicMin(&omin[i], lo);
+    atomicMax(&omax[i], hi);
+    atomicAdd(&cnt[i], k);
+  }
+}
+
 // keys handed to a host-side collective: signed 64-bit MIN must order them like unsigned MIN, so
 // the all-ones "no winner" key becomes INT64_MAX (still >= FLT_MAX in its distance half)
 __global__ void k_clamp_keys(uint64_t *__restrict__ keys, int64_t n) {

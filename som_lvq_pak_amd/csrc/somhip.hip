@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,17 @@ static int fail(const char *fmt, ...) {
     int rc_ = (expr);      \
     if (rc_) return rc_;   \
   } while (0)
+
+// No C++ exception may cross the C ABI (the header promises "nothing here aborts"): every extern "C" body is a
+// function-try-block that ends in one of these.  The HIP runtime itself throws on some misuse (a destroyed
+// stream handle gave std::bad_variant_access out of hipStreamSynchronize).
+static int abi_caught(const char *who) {
+  try { throw; }
+  catch (const std::exception &ex) { return fail("%s: C++ exception: %s", who, ex.what()); }
+  catch (...) { return fail("%s: unknown C++ exception", who); }
+}
+#define ABI_CATCH(name) catch (...) { return abi_caught(#name); }
+#define ABI_CATCH_VOID(name) catch (...) { (void)abi_caught(#name); }
 
 extern "C" const char *somhip_last_error(void) { return g_err.c_str(); }
 extern "C" int somhip_version(void) { return SOMHIP_VERSION; }
@@ -115,6 +127,11 @@ struct somhip_engine {
   // reusable device scratch
   void *scratch[20] = {nullptr};
   size_t scratch_bytes[20] = {0};
+  // the mirrors created on this engine: destroying the engine first releases their device memory and orphans
+  // them (their own destroy then only frees the host struct; any other call on them fails with a message)
+  std::vector<somhip_codebook *> codebooks;
+  std::vector<somhip_dataset *> datasets;
+  bool lvq_apply_attr_set = false;             // hipFuncSetAttribute(k_lvq_batch_apply, ...) done on this device
 };
 
 static int engine_scratch(somhip_engine *e, int slot, size_t bytes, void **out) {
@@ -192,7 +209,10 @@ struct LaunchTimer {   // HIP events on the engine's own stream around one launc
 // ---------------------------------------------------------------------------------
 // engine
 // ---------------------------------------------------------------------------------
-extern "C" int somhip_engine_create(int device, somhip_engine **out) {
+static void codebook_release(somhip_codebook *cb);   // device memory of a mirror (defined with the mirrors below)
+static void dataset_release(somhip_dataset *ds);
+
+extern "C" int somhip_engine_create(int device, somhip_engine **out) try {
   if (!out) return fail("somhip_engine_create: null out");
   int ndev = 0;
   hipError_t er = hipGetDeviceCount(&ndev);
@@ -203,17 +223,25 @@ extern "C" int somhip_engine_create(int device, somhip_engine **out) {
   HIPCHK(hipSetDevice(device));
   somhip_engine *e = new somhip_engine();
   e->device = device;
-  HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  if (const char *ts = getenv("SOMHIP_TAU_SCALE")) { double v = atof(ts); if (v >= 1.0) e->tau_scale = v; }
-  HIPCHK(hipMalloc((void **)&e->d_stats, (8 + 128) * sizeof(unsigned long long)));   // + 64 {rows, pairs} update counters
-  HIPCHK(hipMemset(e->d_stats, 0, (8 + 128) * sizeof(unsigned long long)));
+  auto init = [&]() -> int {
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    if (const char *ts = getenv("SOMHIP_TAU_SCALE")) { double v = atof(ts); if (v >= 1.0) e->tau_scale = v; }
+    HIPCHK(hipMalloc((void **)&e->d_stats, (8 + 128) * sizeof(unsigned long long)));   // + 64 {rows, pairs} update counters
+    HIPCHK(hipMemset(e->d_stats, 0, (8 + 128) * sizeof(unsigned long long)));
+    return 0;
+  };
+  if (int rc = init()) { somhip_engine_destroy(e); return rc; }
   *out = e;
   return 0;
-}
-extern "C" void somhip_engine_destroy(somhip_engine *e) {
+} ABI_CATCH(somhip_engine_create)
+extern "C" void somhip_engine_destroy(somhip_engine *e) try {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  (void)hipStreamSynchronize(e->stream);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  // mirrors that outlive their engine become orphans: their device memory goes now, their handles stay valid
+  // for somhip_codebook_destroy / somhip_dataset_destroy (any order of the destroy calls is fine)
+  for (auto *cb : e->codebooks) codebook_release(cb);     // (these also clear the mirror's engine pointer)
+  for (auto *ds : e->datasets) dataset_release(ds);
   for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->pool) (void)hipEventDestroy(ev);
   for (int i = 0; i < 20; i++) if (e->scratch[i]) (void)hipFree(e->scratch[i]);
@@ -223,68 +251,73 @@ extern "C" void somhip_engine_destroy(somhip_engine *e) {
     if (e->pin_buf[i]) (void)hipHostFree(e->pin_buf[i]);
     if (e->pin_ev[i]) (void)hipEventDestroy(e->pin_ev[i]);
   }
-  (void)hipStreamDestroy(e->stream);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
-}
+} ABI_CATCH_VOID(somhip_engine_destroy)
 extern "C" void *somhip_engine_stream(somhip_engine *e) { return e ? (void *)e->stream : nullptr; }
-extern "C" int somhip_engine_sync(somhip_engine *e) {
+extern "C" int somhip_engine_sync(somhip_engine *e) try {
+  if (!e) return fail("somhip_engine_sync: null engine");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
-}
-extern "C" int somhip_engine_set_scan_mode(somhip_engine *e, int mode) {
+} ABI_CATCH(somhip_engine_sync)
+extern "C" int somhip_engine_set_scan_mode(somhip_engine *e, int mode) try {
   if (mode != SOMHIP_SCAN_DIRECT && mode != SOMHIP_SCAN_MFMA && mode != SOMHIP_SCAN_MFMA_BF16) return fail("somhip_engine_set_scan_mode: bad mode %d", mode);
   e->scan_mode = mode;
   return 0;
-}
-extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[6]) {
+} ABI_CATCH(somhip_engine_set_scan_mode)
+extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[6]) try {
   unsigned long long h[8 + 128];
   HIPCHK(hipMemcpyAsync(h, e->d_stats, sizeof h, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   for (int k = 0; k < 64; k++) { h[3] += h[8 + 2 * k]; h[4] += h[8 + 2 * k + 1]; }
   out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = e->samples_searched; out[4] = h[3]; out[5] = h[4];
   return 0;
-}
-extern "C" int somhip_lvq_stats(somhip_engine *e, uint64_t out[8]) {
+} ABI_CATCH(somhip_scan_stats)
+extern "C" int somhip_lvq_stats(somhip_engine *e, uint64_t out[8]) try {
   if (!e || !out) return fail("somhip_lvq_stats: null argument");
   out[0] = e->lvq_batches; out[1] = e->lvq_samples; out[2] = e->lvq_stop_list; out[3] = e->lvq_stop_cache;
   for (int k = 0; k < 4; k++) out[4 + k] = e->lvq_cycles[k];
   return 0;
-}
-extern "C" int somhip_timing_enable(somhip_engine *e, int on) { CHK(timing_flush(e)); e->timing = on != 0; return 0; }
+} ABI_CATCH(somhip_lvq_stats)
+extern "C" int somhip_timing_enable(somhip_engine *e, int on) try {
+  CHK(timing_flush(e));
+  e->timing = on != 0;
+  return 0;
+} ABI_CATCH(somhip_timing_enable)
 extern "C" int somhip_timing_select(somhip_engine *e, uint64_t kernel_mask) { e->timing_mask = kernel_mask; return 0; }
-extern "C" int somhip_timing_reset(somhip_engine *e) {
+extern "C" int somhip_timing_reset(somhip_engine *e) try {
   CHK(timing_flush(e));
   for (int i = 0; i < KID_COUNT; i++) { e->launches[i] = 0; e->total_ms[i] = 0; }
   return 0;
-}
-extern "C" int somhip_timing_get(somhip_engine *e, int k, int64_t *launches, double *total_ms) {
+} ABI_CATCH(somhip_timing_reset)
+extern "C" int somhip_timing_get(somhip_engine *e, int k, int64_t *launches, double *total_ms) try {
   if (k < 0 || k >= KID_COUNT) return fail("somhip_timing_get: bad kernel id %d", k);
   CHK(timing_flush(e));
   if (launches) *launches = e->launches[k];
   if (total_ms) *total_ms = e->total_ms[k];
   return 0;
-}
-extern "C" int somhip_device_alloc(somhip_engine *e, int64_t bytes, void **p) {
+} ABI_CATCH(somhip_timing_get)
+extern "C" int somhip_device_alloc(somhip_engine *e, int64_t bytes, void **p) try {
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipMalloc(p, (size_t)std::max<int64_t>(bytes, 16)));
   return 0;
-}
-extern "C" int somhip_device_free(somhip_engine *e, void *p) {
+} ABI_CATCH(somhip_device_alloc)
+extern "C" int somhip_device_free(somhip_engine *e, void *p) try {
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipFree(p));
   return 0;
-}
-extern "C" int somhip_copy_to_host(somhip_engine *e, void *dst, const void *src, int64_t bytes) {
+} ABI_CATCH(somhip_device_free)
+extern "C" int somhip_copy_to_host(somhip_engine *e, void *dst, const void *src, int64_t bytes) try {
   HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
-}
-extern "C" int somhip_copy_to_device(somhip_engine *e, void *dst, const void *src, int64_t bytes) {
+} ABI_CATCH(somhip_copy_to_host)
+extern "C" int somhip_copy_to_device(somhip_engine *e, void *dst, const void *src, int64_t bytes) try {
   HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
-}
+} ABI_CATCH(somhip_copy_to_device)
 
 // ---------------------------------------------------------------------------------
 // codebook / dataset mirrors
@@ -299,7 +332,8 @@ struct somhip_codebook {
   float *d_cn = nullptr;           // [ngroups*64] squared row norms (MFMA pre-filter)
   unsigned int *d_cnmax = nullptr; // bits of max squared norm
   uint4 *d_chi = nullptr, *d_clo = nullptr;   // bf16 hi/lo tiles [ngroups][d8][64] (bf16 pre-filter)
-  bool prep_current = false;       // one-shot: the caller has just brought d_cn/d_chi/d_clo up to date itself
+  bool prep_valid = false;         // d_cn / d_chi / d_clo describe the rows as they are now (set by a full k_prep_codes_bf16,
+                                   // kept by the LVQ engine when it re-splits exactly the rows it corrected, cleared by every other writer)
 };
 struct somhip_dataset {
   somhip_engine *e = nullptr;
@@ -316,7 +350,7 @@ struct somhip_dataset {
 
 static int upload_rows(somhip_codebook *cb, const float *rows) {
   somhip_engine *e = cb->e;
-  cb->prep_current = false;
+  cb->prep_valid = false;
   void *stage;
   size_t bytes = sizeof(float) * (size_t)cb->v.n * cb->v.d;
   CHK(engine_scratch(e, 0, bytes, &stage));
@@ -344,6 +378,7 @@ static int codebook_create(somhip_engine *e, const float *rows, const int32_t *l
   HIPCHK(hipSetDevice(e->device));
   somhip_codebook *cb = new somhip_codebook();
   cb->e = e;
+  e->codebooks.push_back(cb);
   cb->v.n = n_rows;
   cb->v.ngroups = (n_rows + WAVE - 1) / WAVE;
   cb->v.d = dim;
@@ -365,13 +400,16 @@ static int codebook_create(somhip_engine *e, const float *rows, const int32_t *l
   cb->ydim = ydim;
   cb->n_global = n_global;
   size_t tile_bytes = (size_t)cb->v.ngroups * cb->v.d4 * WAVE * 4 * sizeof(float);
-  HIPCHK(hipMalloc((void **)&cb->v.tiles, tile_bytes));
-  int rc = upload_rows(cb, rows);
-  if (rc) { somhip_codebook_destroy(cb); return rc; }
-  if (labels) {
-    HIPCHK(hipMalloc((void **)&cb->d_labels, sizeof(int32_t) * (size_t)n_rows));
-    HIPCHK(hipMemcpy(cb->d_labels, labels, sizeof(int32_t) * (size_t)n_rows, hipMemcpyHostToDevice));
-  }
+  auto fill = [&]() -> int {
+    HIPCHK(hipMalloc((void **)&cb->v.tiles, tile_bytes));
+    CHK(upload_rows(cb, rows));
+    if (labels) {
+      HIPCHK(hipMalloc((void **)&cb->d_labels, sizeof(int32_t) * (size_t)n_rows));
+      HIPCHK(hipMemcpy(cb->d_labels, labels, sizeof(int32_t) * (size_t)n_rows, hipMemcpyHostToDevice));
+    }
+    return 0;
+  };
+  if (int rc = fill()) { somhip_codebook_destroy(cb); return rc; }
   *out = cb;
   return 0;
 }
@@ -379,9 +417,9 @@ static int codebook_create(somhip_engine *e, const float *rows, const int32_t *l
 extern "C" int somhip_codebook_create(somhip_engine *e, const float *rows, const int32_t *labels,
                                       int64_t n_rows, int dim, int topol, int neigh, int xdim,
                                       int ydim, int64_t row_offset, int64_t n_global,
-                                      somhip_codebook **out) {
+                                      somhip_codebook **out) try {
   return codebook_create(e, rows, labels, n_rows, dim, topol, neigh, xdim, ydim, row_offset, n_global, 1, 0, out);
-}
+} ABI_CATCH(somhip_codebook_create)
 
 // Interleaved shards of a map: the map is cut into 8x8-unit patches, numbered row-major; shard s of S owns
 // patches s, s+S, s+2S, ...  -- every shard sees every region of the map, so the neighbourhood updates of a
@@ -395,7 +433,7 @@ static int shard_patch_count(int xdim, int ydim, int shard_index, int shard_coun
   return 0;
 }
 extern "C" int somhip_shard_units(int xdim, int ydim, int shard_index, int shard_count, int64_t *units,
-                                  int64_t *n_units) {
+                                  int64_t *n_units) try {
   int64_t np = 0;
   CHK(shard_patch_count(xdim, ydim, shard_index, shard_count, &np));
   if (n_units) *n_units = np * 64;
@@ -404,10 +442,10 @@ extern "C" int somhip_shard_units(int xdim, int ydim, int shard_index, int shard
   v.xdim = xdim; v.patch_w = xdim / 8; v.patch_stride = shard_count; v.patch_phase = shard_index;
   for (int64_t r = 0; r < np * 64; r++) units[r] = shard_count == 1 ? r : (int64_t)unit_of_row(v, r);   // one shard = the whole map, unit order
   return 0;
-}
+} ABI_CATCH(somhip_shard_units)
 extern "C" int somhip_codebook_create_interleaved(somhip_engine *e, const float *rows, int64_t n_rows, int dim,
                                                   int topol, int neigh, int xdim, int ydim, int shard_index,
-                                                  int shard_count, somhip_codebook **out) {
+                                                  int shard_count, somhip_codebook **out) try {
   if (topol < SOMHIP_TOPOL_HEXA) return fail("somhip_codebook_create_interleaved: maps only");
   int64_t np = 0;
   CHK(shard_patch_count(xdim, ydim, shard_index, shard_count, &np));
@@ -415,12 +453,16 @@ extern "C" int somhip_codebook_create_interleaved(somhip_engine *e, const float 
                                      shard_index, shard_count, xdim, ydim, (long long)(np * 64), (long long)n_rows);
   return codebook_create(e, rows, nullptr, n_rows, dim, topol, neigh, xdim, ydim, 0, (int64_t)xdim * ydim,
                          shard_count > 1 ? shard_count : 1, shard_count > 1 ? shard_index : 0, out);
-}
-extern "C" int somhip_codebook_upload(somhip_codebook *cb, const float *rows) {
+} ABI_CATCH(somhip_codebook_create_interleaved)
+extern "C" int somhip_codebook_upload(somhip_codebook *cb, const float *rows) try {
+  if (!cb || !rows) return fail("somhip_codebook_upload: null argument");
+  if (!cb->e) return fail("somhip_codebook_upload: the engine of this codebook was destroyed");
   HIPCHK(hipSetDevice(cb->e->device));
   return upload_rows(cb, rows);
-}
-extern "C" int somhip_codebook_download(somhip_codebook *cb, float *rows) {
+} ABI_CATCH(somhip_codebook_upload)
+extern "C" int somhip_codebook_download(somhip_codebook *cb, float *rows) try {
+  if (!cb || !rows) return fail("somhip_codebook_download: null argument");
+  if (!cb->e) return fail("somhip_codebook_download: the engine of this codebook was destroyed");
   somhip_engine *e = cb->e;
   HIPCHK(hipSetDevice(e->device));
   void *stage;
@@ -435,11 +477,8 @@ extern "C" int somhip_codebook_download(somhip_codebook *cb, float *rows) {
   HIPCHK(hipMemcpyAsync(rows, stage, bytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
-}
-extern "C" void somhip_codebook_destroy(somhip_codebook *cb) {
-  if (!cb) return;
-  (void)hipSetDevice(cb->e->device);
-  (void)hipStreamSynchronize(cb->e->stream);
+} ABI_CATCH(somhip_codebook_download)
+static void codebook_release(somhip_codebook *cb) {
   if (cb->v.tiles) (void)hipFree(cb->v.tiles);
   if (cb->d_labels) (void)hipFree(cb->d_labels);
   if (cb->d_talpha) (void)hipFree(cb->d_talpha);
@@ -447,24 +486,39 @@ extern "C" void somhip_codebook_destroy(somhip_codebook *cb) {
   if (cb->d_cnmax) (void)hipFree(cb->d_cnmax);
   if (cb->d_chi) (void)hipFree(cb->d_chi);
   if (cb->d_clo) (void)hipFree(cb->d_clo);
-  delete cb;
+  cb->v.tiles = nullptr;
+  cb->d_labels = nullptr; cb->d_talpha = nullptr; cb->d_cn = nullptr; cb->d_cnmax = nullptr;
+  cb->d_chi = cb->d_clo = nullptr;
+  cb->e = nullptr;
 }
+extern "C" void somhip_codebook_destroy(somhip_codebook *cb) try {
+  if (!cb) return;
+  if (somhip_engine *e = cb->e) {                       // an orphan (engine destroyed first) has nothing left on the device
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    codebook_release(cb);
+    e->codebooks.erase(std::remove(e->codebooks.begin(), e->codebooks.end(), cb), e->codebooks.end());
+  }
+  delete cb;
+} ABI_CATCH_VOID(somhip_codebook_destroy)
 
 extern "C" int somhip_dataset_create(somhip_engine *e, const float *rows, int64_t n_rows, int dim,
                                      const uint8_t *mask, const int32_t *labels,
                                      const int16_t *weight, const int16_t *fixed_xy,
-                                     somhip_dataset **out) {
+                                     somhip_dataset **out) try {
   if (!e || !rows || !out) return fail("somhip_dataset_create: null argument");
   if (n_rows <= 0 || dim <= 0) return fail("somhip_dataset_create: empty data set");
   HIPCHK(hipSetDevice(e->device));
   somhip_dataset *ds = new somhip_dataset();
   ds->e = e; ds->n = n_rows; ds->d = dim; ds->owns_rows = true;
+  e->datasets.push_back(ds);
+  auto fill = [&]() -> int {
   size_t bytes = sizeof(float) * (size_t)n_rows * dim;
   float *dr = nullptr;
   // 16 spare bytes: wave-uniform float4 reads of the last row never leave the buffer
   HIPCHK(hipMalloc((void **)&dr, bytes + 16));
-  HIPCHK(hipMemcpy(dr, rows, bytes, hipMemcpyHostToDevice));
   ds->d_rows = dr;
+  HIPCHK(hipMemcpy(dr, rows, bytes, hipMemcpyHostToDevice));
   if (mask) {
     bool any = false;
     ds->all_masked.assign((size_t)n_rows, 0);
@@ -483,28 +537,42 @@ extern "C" int somhip_dataset_create(somhip_engine *e, const float *rows, int64_
   }
   if (labels) ds->labels.assign(labels, labels + n_rows);
   if (weight) ds->weight.assign(weight, weight + n_rows);
-  if (fixed_xy) ds->fixed_xy.assign(fixed_xy, fixed_xy + 2 * n_rows);
+  if (fixed_xy) {
+    // -1,-1 = no fixed point; a negative coordinate is how "none" is written, so it cannot also be a position
+    for (int64_t r = 0; r < n_rows; r++)
+      if ((fixed_xy[2 * r] < 0) != (fixed_xy[2 * r + 1] < 0) || fixed_xy[2 * r] < -1 || fixed_xy[2 * r + 1] < -1)
+        return fail("somhip_dataset_create: fixed point (%d,%d) of row %lld: negative coordinates are not supported",
+                    fixed_xy[2 * r], fixed_xy[2 * r + 1], (long long)r);
+    ds->fixed_xy.assign(fixed_xy, fixed_xy + 2 * n_rows);
+  }
+  return 0;
+  };
+  if (int rc = fill()) { somhip_dataset_destroy(ds); return rc; }
   *out = ds;
   return 0;
-}
+} ABI_CATCH(somhip_dataset_create)
 extern "C" int somhip_dataset_wrap_device(somhip_engine *e, const float *dev_rows, int64_t n_rows,
-                                          int dim, somhip_dataset **out) {
+                                          int dim, somhip_dataset **out) try {
   if (!e || !dev_rows || !out) return fail("somhip_dataset_wrap_device: null argument");
+  if (n_rows <= 0 || dim <= 0) return fail("somhip_dataset_wrap_device: empty data set");
   somhip_dataset *ds = new somhip_dataset();
   ds->e = e; ds->n = n_rows; ds->d = dim; ds->d_rows = dev_rows; ds->owns_rows = false;
+  e->datasets.push_back(ds);
   *out = ds;
   return 0;
-}
+} ABI_CATCH(somhip_dataset_wrap_device)
 extern "C" int somhip_dataset_generate(somhip_engine *e, uint64_t seed, int k_centres, int dim, int64_t first_row,
-                                       int64_t n_rows, int32_t *centres, somhip_dataset **out) {
+                                       int64_t n_rows, int32_t *centres, somhip_dataset **out) try {
   if (!e || !out) return fail("somhip_dataset_generate: null argument");
   if (k_centres <= 0 || dim <= 0 || n_rows <= 0 || first_row < 0) return fail("somhip_dataset_generate: bad shape");
   HIPCHK(hipSetDevice(e->device));
   somhip_dataset *ds = new somhip_dataset();
   ds->e = e; ds->n = n_rows; ds->d = dim; ds->owns_rows = true;
-  float *rows = nullptr;
+  e->datasets.push_back(ds);
   int32_t *dcen = nullptr;
-  HIPCHK(hipMalloc((void **)&rows, sizeof(float) * (size_t)n_rows * dim));
+  auto fill = [&]() -> int {
+  float *rows = nullptr;
+  HIPCHK(hipMalloc((void **)&rows, sizeof(float) * (size_t)n_rows * dim + 16));   // same 16 spare bytes as dataset_create
   ds->d_rows = rows;
   if (centres) HIPCHK(hipMalloc((void **)&dcen, sizeof(int32_t) * (size_t)n_rows));
   const int64_t total = n_rows * dim;
@@ -518,19 +586,32 @@ extern "C" int somhip_dataset_generate(somhip_engine *e, uint64_t seed, int k_ce
     HIPCHK(hipMemcpyAsync(centres, dcen, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     ds->labels.assign(centres, centres + n_rows);
-    HIPCHK(hipFree(dcen));
   }
+  return 0;
+  };
+  const int rc = fill();
+  if (dcen) (void)hipFree(dcen);
+  if (rc) { somhip_dataset_destroy(ds); return rc; }
   *out = ds;
   return 0;
-}
-extern "C" void somhip_dataset_destroy(somhip_dataset *ds) {
-  if (!ds) return;
-  (void)hipSetDevice(ds->e->device);
-  (void)hipStreamSynchronize(ds->e->stream);
+} ABI_CATCH(somhip_dataset_generate)
+static void dataset_release(somhip_dataset *ds) {
   if (ds->owns_rows && ds->d_rows) (void)hipFree((void *)ds->d_rows);
   if (ds->d_mask) (void)hipFree(ds->d_mask);
-  delete ds;
+  ds->d_rows = nullptr;
+  ds->d_mask = nullptr;
+  ds->e = nullptr;
 }
+extern "C" void somhip_dataset_destroy(somhip_dataset *ds) try {
+  if (!ds) return;
+  if (somhip_engine *e = ds->e) {
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    dataset_release(ds);
+    e->datasets.erase(std::remove(e->datasets.begin(), e->datasets.end(), ds), e->datasets.end());
+  }
+  delete ds;
+} ABI_CATCH_VOID(somhip_dataset_destroy)
 
 // the rest of the host side, by stage (same translation unit)
 #include "host_scan.inc"

@@ -243,6 +243,51 @@ def gen_rows(seed, k_centres, dim, first_row, n_rows):
     return x.astype(np.float32), cen.astype(np.int32)
 
 
+def column_minmax(ds):
+    """Per-component (lo, hi, count) of the unmasked data on the device (somhip_column_minmax)."""
+    lo = np.empty(ds.dim, dtype=np.float32)
+    hi = np.empty(ds.dim, dtype=np.float32)
+    cnt = np.empty(ds.dim, dtype=np.int64)
+    check(ds.e.lib.somhip_column_minmax(ds.h, _p(lo, _lib.c_float_p), _p(hi, _lib.c_float_p), _p(cnt, _lib.c_i64_p)))
+    return lo, hi, cnt
+
+
+def orand_stream(seed, count):
+    """The reference's LCG (lvq_pak.c:459-473: next = next * 23 % 100000001, value = next % 32767) as a numpy
+    array of `count` draws after init_random(seed): state_k = seed * 23^k mod M, evaluated blockwise."""
+    M = np.uint64(100000001)
+    blk = 1 << 12
+    pw = np.empty(blk, dtype=np.uint64)                 # 23^(i+1) mod M
+    v = 1
+    for i in range(blk):
+        v = v * 23 % 100000001
+        pw[i] = v
+    nblk = (count + blk - 1) // blk
+    base = np.empty(nblk, dtype=np.uint64)              # state before block j
+    s = int(seed) % 100000001
+    step = int(pw[-1])
+    for j in range(nblk):
+        base[j] = s
+        s = s * step % 100000001
+    st = (base[:, None] * pw[None, :]) % M
+    return (st.reshape(-1)[:count] % np.uint64(32767)).astype(np.int64)
+
+
+def randinit_from_bbox(lo, hi, cnt, xdim, ydim, seed):
+    """randinit_codes (som_rout.c:98-150) from the data's bounding box: maximum seeded with FLT_MIN, minimum with
+    FLT_MAX (:108-111), then unit by unit, component by component lo + (hi - lo) * ((float)orand() / 32768.0)
+    evaluated in double and stored as float (:140-150); components without data get 0."""
+    lo = np.minimum(np.asarray(lo, dtype=np.float32), np.float32(3.402823466e+38))
+    hi = np.maximum(np.asarray(hi, dtype=np.float32), np.float32(1.17549435e-38))
+    d = lo.shape[0]
+    n = xdim * ydim
+    r = orand_stream(seed, n * d).reshape(n, d).astype(np.float32).astype(np.float64) / 32768.0
+    span = (hi - lo).astype(np.float32).astype(np.float64)
+    out = (lo.astype(np.float64)[None, :] + span[None, :] * r).astype(np.float32)
+    out[:, np.asarray(cnt) == 0] = 0.0
+    return out
+
+
 def find_winners(cb, ds, first=0, count=None, knn=1, tie=TIE_FIRST):
     """WINNER_FUNCTION over data rows [first, first+count): (index, diff, ret)."""
     count = ds.n if count is None else count

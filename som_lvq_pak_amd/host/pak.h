@@ -54,6 +54,7 @@ struct entries {
   long buffer;                  /* > 0 with random_order: -buffer N -rand, rows are presented buffer by buffer, */
   int random_order;             /*   each buffer reshuffled when it is (re)loaded (datafile.c:237-344)            */
   void *userdata;               /* device mirror handle (as lvq_pak.h:112) */
+  unsigned long mirror_generation;   /* host-row generation the mirror was uploaded at (paklib.c, per-sample surface) */
 };
 
 struct winner_info { long index; struct data_entry *winner; float diff; };

@@ -531,6 +531,7 @@ fail:
 void close_entries(struct entries *e)
 {
   if (!e) return;
+  if (e->userdata) somhip_codebook_destroy(e->userdata);     /* the per-sample surface's mirror (an orphan if the engine went first) */
   for (long r = 0; r < e->num_entries; r++) free(e->rows[r].labels);
   free(e->rows); free(e->points); free(e->masks); free(e->fixed_xy); free(e->weights);
   free(e);
@@ -768,12 +769,48 @@ static somhip_dataset *mirror_data(struct entries *data, int with_labels)
   return ds;
 }
 
-/* per-sample WINNER_FUNCTION of the "hip" row: one sample through the same kernels.  Tools
- * should prefer the epoch-level functions; this keeps per-sample callers working. */
+/* The per-sample surface of the "hip" row (lvq_pak.h:131-148).  Tools should use the epoch-level functions; these
+ * keep per-sample callers of the registry working (balance.c:56, som_rout.c:741,785 dereference dist; the
+ * reference's own loops call winner and vector_adapt once per sample).
+ *
+ * dist / vector_adapt act on ONE host row each -- the host list owns the rows (SURVEY 8b "Ownership") and a
+ * PCIe round trip per row would cost a thousand times the arithmetic -- so they are the reference's own
+ * expressions on the host rows: vector_dist_euc (lvq_pak.c:291-316) and adapt_vector (lvq_pak.c:339-351),
+ * compiled without contraction.  A row written by vector_adapt makes every device mirror stale: the generation
+ * counter below makes the next winner call re-upload its codebook. */
+static unsigned long host_rows_generation = 0;
+
+static float hip_row_dist(struct data_entry *v1, struct data_entry *v2, int dim)
+{
+  float sum = 0.0f;
+  int masked = 0;
+  for (int i = 0; i < dim; i++) {
+    if ((v1->mask && v1->mask[i]) || (v2->mask && v2->mask[i])) { masked++; continue; }
+    float t = v1->points[i] - v2->points[i];
+    sum += t * t;
+  }
+  if (masked == dim) return -1.0f;                    /* nothing to compare (lvq_pak.c:312-313) */
+  return (float)sqrt((double)sum);
+}
+
+static void hip_row_adapt(struct data_entry *code, struct data_entry *sample, int dim, float alpha)
+{
+  for (int i = 0; i < dim; i++) {
+    if (sample->mask && sample->mask[i]) continue;    /* only the sample's mask counts (lvq_pak.c:345-346) */
+    code->points[i] += alpha * (sample->points[i] - code->points[i]);
+  }
+  host_rows_generation++;
+}
+
 static int hip_find_winner(struct entries *codes, struct data_entry *sample, struct winner_info *w, int knn)
 {
-  somhip_codebook *cb = codes->userdata ? codes->userdata : (codes->userdata = mirror_codes(codes, 0));
+  somhip_codebook *cb = codes->userdata;
+  if (!cb) { cb = codes->userdata = mirror_codes(codes, 0); codes->mirror_generation = host_rows_generation; }
   if (!cb) return 0;
+  if (codes->mirror_generation != host_rows_generation) {       /* rows were adapted on the host since the upload */
+    if (somhip_codebook_upload(cb, codes->points)) { fprintf(stderr, "%s\n", somhip_last_error()); return 0; }
+    codes->mirror_generation = host_rows_generation;
+  }
   somhip_dataset *ds = NULL;
   int32_t idx[8], ret = 0;
   float diff[8];
@@ -795,7 +832,8 @@ static int hip_find_winner(struct entries *codes, struct data_entry *sample, str
  * "default" is accepted as an alias so existing command lines run unchanged.  Unknown names
  * warn and fall back exactly as the reference does. */
 static struct vec_functions { const char *name; DIST_FUNCTION *dist; VECTOR_ADAPT *vector_adapt; WINNER_FUNCTION *winner; }
-vec_funcs[] = { {"hip", NULL, NULL, hip_find_winner}, {"default", NULL, NULL, hip_find_winner}, {NULL, NULL, NULL, NULL} };
+vec_funcs[] = { {"hip", hip_row_dist, hip_row_adapt, hip_find_winner}, {"default", hip_row_dist, hip_row_adapt, hip_find_winner},
+                {NULL, NULL, NULL, NULL} };
 
 int set_teach_params(struct teach_params *p, struct entries *codes, struct entries *data, const char *funcname)
 {
@@ -836,8 +874,9 @@ static int save_snapshot(struct teach_params *teach, long iter)   /* lvq_pak.c:6
 static long segment_end(struct teach_params *t, long start)
 {
   if (!t->snapshot || t->snapshot->interval <= 0) return t->length;
-  long next = (start / t->snapshot->interval + 1) * t->snapshot->interval;   /* next le with le % iv == 0, le > start-1 */
-  if (start == 0) next = t->snapshot->interval;
+  const long iv = t->snapshot->interval;
+  long next = (start + iv - 1) / iv * iv;             /* smallest le >= start with le % iv == 0 ... */
+  if (next == 0) next = iv;                           /* ... and le > 0 (som_rout.c:650) */
   long end = next + 1;
   return end < t->length ? end : t->length;
 }

@@ -91,6 +91,24 @@ def buffer_golden(exp, d):
             run(tool, "-din", d(data), "-cin", cin, "-cout", out, *args)
             res[tag] = {"tool": tool, "data": data, "cin": cin, "args": [str(a) for a in args], "md5": md5(out)}
     exp["buffer_rand"] = res
+    # -buffer N together with -snapinterval: segments cut by the buffer feed may start exactly on a snapshot
+    # iteration (som_rout.c:650, lvq_rout.c:559 save after every le % interval == 0, le > 0)
+    snaps = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, tool, data, cin, args, its in (
+                ("vsom_b1000_snap1000", "vsom", "ex.dat", "som_init_hexa_bubble.cod",
+                 ["-rlen", 4500, "-alpha", 0.05, "-radius", 10, "-rand", 5, "-buffer", 1000, "-snapinterval", 1000], (1000, 2000, 3000, 4000)),
+                ("vsom_snap1", "vsom", "ex.dat", "som_init_hexa_bubble.cod",
+                 ["-rlen", 6, "-alpha", 0.05, "-radius", 10, "-snapinterval", 1], (1, 2, 3, 4, 5)),
+                ("lvq1_b500_snap250", "lvq1", "ex1.dat", "lvq_init.cod",
+                 ["-rlen", 1200, "-alpha", 0.05, "-rand", 3, "-buffer", 500, "-snapinterval", 250], (250, 500, 750, 1000))):
+            out = os.path.join(tmp, tag + ".cod")
+            run(tool, "-din", d(data), "-cin", cin, "-cout", out, *args, "-snapfile", os.path.join(tmp, tag + "_%ld.snap"))
+            files = sorted(f for f in os.listdir(tmp) if f.startswith(tag + "_") and f.endswith(".snap"))
+            assert files == sorted("%s_%d.snap" % (tag, i) for i in its), files
+            snaps[tag] = {"tool": tool, "data": data, "cin": cin, "args": [str(a) for a in args], "md5": md5(out),
+                          "snapshots": {str(i): md5(os.path.join(tmp, "%s_%d.snap" % (tag, i))) for i in its}}
+    exp["buffer_snap"] = snaps
 
 
 def lininit_golden(exp, d):

@@ -63,6 +63,21 @@ def test_fast_number_parser_equals_sscanf(tools, tmp_path):
     assert p.returncode == 0 and p.stdout.strip().endswith("mismatches 0"), p.stdout
 
 
+def test_registry_row_dist_and_adapt_equal_the_oracle(tools, tmp_path):
+    """the "hip" row fills all three pointers of the reference's registry (datafile.c:1217-1220); its per-row
+    dist / vector_adapt give the bits of vector_dist_euc / adapt_vector (oracle restatement) on masked rows"""
+    exe = str(tmp_path / "row_funcs_check")
+    host = os.path.join(ROOT, "som_lvq_pak_amd", "host")
+    orc = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["make", "-s", "-C", orc, "oracle"])
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-I", host, "-I", os.path.join(ROOT, "include"), "-I", orc, "-o", exe,
+                           os.path.join(ROOT, "tests", "helpers", "row_funcs_check.c"), os.path.join(host, "paklib.c"),
+                           "-L", os.path.join(ROOT, "som_lvq_pak_amd"), "-lsomhip", "-L", orc, "-loracle",
+                           "-Wl,-rpath," + os.path.join(ROOT, "som_lvq_pak_amd"), "-Wl,-rpath," + orc, "-lm"])
+    p = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and p.stdout.strip().endswith("mismatches 0"), p.stdout
+
+
 def test_tools_refuse_without_gpu(tools, tmp_path):
     import torch
     if torch.cuda.is_available():
@@ -272,6 +287,22 @@ def test_buffer_with_rand_matches_reference_cli(tools, tmp_path):
         run(ex["tool"], "-din", os.path.join(DATA, ex["data"]), "-cin", os.path.join(CLI, ex["cin"]), "-cout", out,
             *ex["args"], "-v", 0)
         assert md5(out) == ex["md5"], tag
+
+
+@pytest.mark.gpu
+def test_buffer_with_snapshots_matches_reference_cli(tools, tmp_path):
+    """-buffer N -snapinterval N (and interval 1): a segment cut by the buffer feed can start exactly on a snapshot
+    iteration; the reference saves after every le % interval == 0, le > 0 (som_rout.c:650, lvq_rout.c:559).
+    Snapshot files and the final codebook byte for byte."""
+    for tag, ex in EXPECTED["buffer_snap"].items():
+        out = tmp_path / (tag + ".cod")
+        run(ex["tool"], "-din", os.path.join(DATA, ex["data"]), "-cin", os.path.join(CLI, ex["cin"]), "-cout", out,
+            *ex["args"], "-snapfile", str(tmp_path / (tag + "_%ld.snap")), "-v", 0)
+        assert md5(out) == ex["md5"], tag
+        made = sorted(f for f in os.listdir(tmp_path) if f.startswith(tag + "_") and f.endswith(".snap"))
+        assert made == sorted("%s_%s.snap" % (tag, i) for i in ex["snapshots"]), (tag, made)
+        for it, want in ex["snapshots"].items():
+            assert md5(tmp_path / ("%s_%s.snap" % (tag, it))) == want, (tag, it)
 
 
 @pytest.mark.gpu

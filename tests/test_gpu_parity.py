@@ -752,3 +752,98 @@ def test_scalar_update_kernel_full_lists(eng, E, oracle, batch, monkeypatch):
     assert ran > 0
     assert np.array_equal(ti, oi) and np.array_equal(bits(td), bits(od))
     assert np.array_equal(bits(cb.download()), bits(oc))
+
+
+# --------------------------------------------------------------------------- round 2: state flags, randinit pass
+def test_prefilter_copies_follow_every_writer(eng, E, oracle):
+    """The bf16 tiles / norms of the MFMA pre-filter are reused while the codebook is unchanged.  Every writer
+    must invalidate them: MFMA scan (full split at S0) -> upload (S1) -> lvq_train on a codebook below 4096 rows
+    (direct top-k: no split; only the corrected rows are re-split) -> MFMA scan.  A stale reuse filters with S0's
+    tiles and can lose the exact winner silently."""
+    n, d, m = 640, 48, 1500
+    x, lab = synth(91, m, d, k=5)
+    rs = np.random.RandomState(5)
+    s0 = (x[rs.randint(0, m, n)] + 0.2 * rs.standard_normal((n, d))).astype(np.float32)
+    s1 = (x[rs.randint(0, m, n)][::-1] * 1.7 - 3.0).astype(np.float32)       # far from s0
+    clab = lab[rs.randint(0, m, n)].astype(np.int32)
+    eng.set_scan_mode("mfma_bf16")
+    cb = E.Codebook(eng, s0, labels=clab)
+    ds = E.Dataset(eng, x, labels=lab)
+    gi, _, _ = E.find_winners(cb, ds)
+    assert np.array_equal(gi, oracle.winners(s0, x)[0])
+    cb.upload(s1)
+    want, _, _, _ = oracle.lvq_train(1, s1, clab, x, lab, 400, 0.05)
+    E.lvq_train(cb, ds, E.LVQ1, 400, 0.05, trace=False)
+    assert np.array_equal(bits(cb.download()), bits(want))
+    gi, gd, _ = E.find_winners(cb, ds)
+    oi, od, _ = oracle.winners(want, x)
+    assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od))
+    # and after SOM-style writers: online and mini-batch training on a map
+    cb.close()
+    ini = oracle.randinit(x, 32, 20, 3)
+    cbm = E.Codebook(eng, ini, E.TOPOL_HEXA, E.NEIGH_BUBBLE, 32, 20)
+    E.find_winners(cbm, ds)
+    for batch in (1, 64):
+        E.som_train(cbm, ds, 300, 0.05, 6.0, batch=batch, trace=False)
+        now = cbm.download()
+        gi, gd, _ = E.find_winners(cbm, ds)
+        oi, od, _ = oracle.winners(now, x)
+        assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od)), batch
+    cbm.close()
+    ds.close()
+
+
+def test_column_minmax_and_randinit_from_device_bbox(eng, E, oracle):
+    """randinit_codes' data pass on the device (som_rout.c:98-131) + the reference's LCG fill: equals the oracle's
+    randinit on host rows, masked components and an all-negative column (FLT_MIN seed of the maximum) included"""
+    rs = np.random.RandomState(17)
+    x = (3.0 * rs.standard_normal((3000, 37)) - 1.0).astype(np.float32)
+    x[:, 5] = -np.abs(x[:, 5]) - 0.5
+    ds = E.Dataset(eng, x)
+    lo, hi, cnt = E.column_minmax(ds)
+    assert np.array_equal(bits(lo), bits(x.min(0))) and np.array_equal(bits(hi), bits(x.max(0))) and (cnt == 3000).all()
+    got = E.randinit_from_bbox(lo, hi, cnt, 11, 7, 123)
+    assert np.array_equal(bits(got), bits(oracle.randinit(x, 11, 7, 123)))
+    mask = (rs.rand(3000, 37) < 0.2).astype(np.uint8)
+    mask[:, 9] = 1
+    dm = E.Dataset(eng, x, mask=mask)
+    lo, hi, cnt = E.column_minmax(dm)
+    xm = np.where(mask == 0, x, np.nan)
+    assert cnt[9] == 0 and np.array_equal(cnt, (mask == 0).sum(0))
+    ok = cnt > 0
+    assert np.array_equal(bits(lo[ok]), bits(np.nanmin(xm[:, ok], 0).astype(np.float32)))
+    assert np.array_equal(bits(hi[ok]), bits(np.nanmax(xm[:, ok], 0).astype(np.float32)))
+    # the generated stream: device rows == host rows, so the box must agree too
+    g = E.Dataset(eng, generate=(3456, 8, 24, 0, 5000))
+    hx, _ = E.gen_rows(3456, 8, 24, 0, 5000)
+    lo, hi, cnt = E.column_minmax(g)
+    assert np.array_equal(bits(lo), bits(hx.min(0))) and np.array_equal(bits(hi), bits(hx.max(0)))
+    for h in (ds, dm, g):
+        h.close()
+
+
+def test_c_host_may_destroy_the_engine_first(tmp_path):
+    """include/somhip.h: "nothing here aborts".  A C host that destroys the engine before its codebook and data set
+    (round 1 aborted with std::bad_variant_access out of hipStreamSynchronize on the freed stream) must run through;
+    calls on the orphans fail with a message (tests/helpers/abi_order.c)."""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "abi_order")
+    lib = os.path.join(ROOT, "som_lvq_pak_amd")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "helpers", "abi_order.c"), "-L", lib, "-lsomhip", "-Wl,-rpath," + lib])
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and "abi_order ok" in p.stdout, (p.returncode, p.stdout, p.stderr)
+
+
+def test_python_mirrors_survive_engine_close_first(E):
+    e2 = E.Engine(0)
+    rows = np.arange(40, dtype=np.float32).reshape(10, 4)
+    cb, ds = E.Codebook(e2, rows), E.Dataset(e2, rows)
+    e2.lib.somhip_engine_destroy(e2.h)           # behind the wrapper's back: the C ABI itself must cope
+    with pytest.raises(Exception, match="destroyed"):
+        E.find_winners(cb, ds)
+    e2.lib.somhip_codebook_destroy(cb.h)
+    e2.lib.somhip_dataset_destroy(ds.h)
+    cb.h = ds.h = e2.h = None
+    e2._children = []
