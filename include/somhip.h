@@ -181,8 +181,10 @@ int  somhip_lvq_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_lvq_
 /* out[0] = codebook rescans (batches) done by somhip_lvq_train so far, out[1] = samples,
  * out[2] / out[3] = batches cut short because a sample's candidate list was exhausted /
  * the on-chip row cache was full, out[4..7] = 100 MHz ticks the in-order kernel spent in
- * its phases (inputs, cached-row distances, decision, correction) */
-int  somhip_lvq_stats(somhip_engine *e, uint64_t out[8]);
+ * its phases (inputs, cached-row distances, decision, correction; summed over the components of a batch),
+ * out[8] = independent components walked, out[9] = sum over the batches of the largest component's size
+ * (the length of the longest serial walk) */
+int  somhip_lvq_stats(somhip_engine *e, uint64_t out[10]);
 
 /* ---- lininit's data passes (find_eigenvectors, som_rout.c:211-289) ----------------
  * sum[i] / count[i]: fp32 sum and number of the unmasked values of component i over all rows in

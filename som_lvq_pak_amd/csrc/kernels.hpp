@@ -28,4 +28,5 @@
 #include "kernels/som_online.hpp"
 #include "kernels/rerank.hpp"
 #include "kernels/lvq.hpp"
+#include "kernels/lvq_batch.hpp"
 #include "kernels/qerror2_lininit.hpp"

@@ -306,10 +306,11 @@ __global__ void k_prep_codes_bf16(CbView cb, int d8, float *__restrict__ cn,
 // row, lanes over the k-blocks; the norm is a wave sum (any summation order satisfies the bound tau
 // is built from)
 __global__ __launch_bounds__(256) void k_prep_rows_bf16(CbView cb, int d8, const int32_t *__restrict__ list,
-                                                        int nlist, float *__restrict__ cn,
+                                                        int nlist, const int32_t *__restrict__ nlist_dev,
+                                                        float *__restrict__ cn,
                                                         uint4 *__restrict__ chi, uint4 *__restrict__ clo) {
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (w >= nlist) return;
+  if (w >= nlist || (nlist_dev && w >= *nlist_dev)) return;     // nlist: launch bound; *nlist_dev: the list's length on the device
   const int64_t row = list[w];
   const int64_t g = row >> 6;
   const int rl = static_cast<int>(row & 63);

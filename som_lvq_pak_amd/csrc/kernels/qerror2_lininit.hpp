@@ -1,7 +1,7 @@
 // kernels/qerror2_lininit.hpp -- K7/K8: find_qerror2, lininit data passes, small utilities
 // (part of kernels.hpp; see the notes at the top of that file)
 #pragma once
-#include "lvq.hpp"
+#include "lvq_batch.hpp"
 
 namespace somhip {
 

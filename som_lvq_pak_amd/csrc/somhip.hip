@@ -79,13 +79,14 @@ enum KernelId {
   KID_DIST_MFMA_BF16,
   KID_LVQ_BATCH_APPLY,
   KID_SOM_UPDATE_BUBBLE_S,
+  KID_LVQ_COMPONENTS,
   KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {
     "k_scan_exact", "k_som_update_run", "k_som_online_step", "k_lvq_online_step",
     "k_pack_samples", "k_merge_topk", "k_scan_masked", "k_layout", "k_decode_winners",
     "k_dist_mfma", "k_rerank", "k_norms_tau", "k_som_members",
-    "k_rerank_select", "k_rerank_pairs", "k_dist_mfma_bf16", "k_lvq_batch_apply", "k_som_update_bubble_s"};
+    "k_rerank_select", "k_rerank_pairs", "k_dist_mfma_bf16", "k_lvq_batch_apply", "k_som_update_bubble_s", "k_lvq_components"};
 extern "C" int somhip_kernel_count(void) { return KID_COUNT; }
 extern "C" const char *somhip_kernel_name(int i) { return (i >= 0 && i < KID_COUNT) ? kKernelNames[i] : ""; }
 
@@ -112,6 +113,7 @@ struct somhip_engine {
   uint64_t samples_searched = 0;
   uint64_t lvq_batches = 0, lvq_samples = 0;   // exact batched LVQ: rescans and samples
   uint64_t lvq_stop_list = 0, lvq_stop_cache = 0, lvq_cycles[4] = {0, 0, 0, 0};   // batches ended by an exhausted candidate list / a full cache
+  uint64_t lvq_components = 0, lvq_largest = 0;   // independent components walked, and the sum of the largest one's size per batch
   // ring of pinned host staging buffers for per-batch scalars (H2D without a host sync)
   void *pin_buf[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pin_bytes[4] = {0, 0, 0, 0};
@@ -125,8 +127,8 @@ struct somhip_engine {
   int64_t launches[KID_COUNT] = {0};
   double total_ms[KID_COUNT] = {0};
   // reusable device scratch
-  void *scratch[20] = {nullptr};
-  size_t scratch_bytes[20] = {0};
+  void *scratch[32] = {nullptr};
+  size_t scratch_bytes[32] = {0};
   // the mirrors created on this engine: destroying the engine first releases their device memory and orphans
   // them (their own destroy then only frees the host struct; any other call on them fails with a message)
   std::vector<somhip_codebook *> codebooks;
@@ -244,7 +246,7 @@ extern "C" void somhip_engine_destroy(somhip_engine *e) try {
   for (auto *ds : e->datasets) dataset_release(ds);
   for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->pool) (void)hipEventDestroy(ev);
-  for (int i = 0; i < 20; i++) if (e->scratch[i]) (void)hipFree(e->scratch[i]);
+  for (int i = 0; i < 32; i++) if (e->scratch[i]) (void)hipFree(e->scratch[i]);
   if (e->d_stats) (void)hipFree(e->d_stats);
   if (e->online_graph_exec) (void)hipGraphExecDestroy(e->online_graph_exec);
   for (int i = 0; i < 4; i++) {
@@ -274,10 +276,11 @@ extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[6]) try {
   out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = e->samples_searched; out[4] = h[3]; out[5] = h[4];
   return 0;
 } ABI_CATCH(somhip_scan_stats)
-extern "C" int somhip_lvq_stats(somhip_engine *e, uint64_t out[8]) try {
+extern "C" int somhip_lvq_stats(somhip_engine *e, uint64_t out[10]) try {
   if (!e || !out) return fail("somhip_lvq_stats: null argument");
   out[0] = e->lvq_batches; out[1] = e->lvq_samples; out[2] = e->lvq_stop_list; out[3] = e->lvq_stop_cache;
   for (int k = 0; k < 4; k++) out[4 + k] = e->lvq_cycles[k];
+  out[8] = e->lvq_components; out[9] = e->lvq_largest;
   return 0;
 } ABI_CATCH(somhip_lvq_stats)
 extern "C" int somhip_timing_enable(somhip_engine *e, int on) try {

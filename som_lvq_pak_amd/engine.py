@@ -66,10 +66,10 @@ class Engine:
 
     def lvq_stats(self):
         """exact batched LVQ: codebook rescans (batches) and samples so far"""
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 10)()
         check(self.lib.somhip_lvq_stats(self.h, out))
         return {"batches": out[0], "samples": out[1], "stop_list": out[2], "stop_cache": out[3],
-                "phase_us": [out[4 + k] / 100.0 for k in range(4)]}
+                "phase_us": [out[4 + k] / 100.0 for k in range(4)], "components": out[8], "largest": out[9]}
 
     # --- timing table (HIP events on the engine's stream) ---
     def timing(self, on=True):

@@ -403,11 +403,13 @@ def _lvq_both_engines(eng, E, oracle, kind, codes, clab, x, lab, length, alpha, 
     """exact batched engine (default) and one-launch-per-iteration engine against the oracle"""
     oc, ol, oi, od = oracle.lvq_train(kind, codes, clab, x, lab, length, alpha, **kw)
     stats = {}
-    for mode in ("batched", "batched_mfma_topk", "online"):
+    for mode in ("batched", "batched_serial", "batched_mfma_topk", "online"):
         if mode == "online":
             os.environ["SOMHIP_LVQ_ONLINE"] = "1"
         if mode == "batched_mfma_topk":
             os.environ["SOMHIP_TOPK_MFMA"] = "1"
+        if mode == "batched_serial":
+            os.environ["SOMHIP_LVQ_SERIAL"] = "1"            # one component: the serial walk of round 1
         try:
             cb = E.Codebook(eng, codes, labels=clab)
             ds = E.Dataset(eng, x, labels=lab)
@@ -417,6 +419,7 @@ def _lvq_both_engines(eng, E, oracle, kind, codes, clab, x, lab, length, alpha, 
         finally:
             os.environ.pop("SOMHIP_LVQ_ONLINE", None)
             os.environ.pop("SOMHIP_TOPK_MFMA", None)
+            os.environ.pop("SOMHIP_LVQ_SERIAL", None)
         assert np.array_equal(ti, oi), mode
         assert np.array_equal(bits(td), bits(od)), mode
         assert np.array_equal(bits(cb.download()), bits(oc)), mode
@@ -425,7 +428,9 @@ def _lvq_both_engines(eng, E, oracle, kind, codes, clab, x, lab, length, alpha, 
         stats[mode] = {k: after[k] - before[k] for k in after if k != "phase_us"}
     assert stats["online"]["batches"] == 0 and stats["online"]["samples"] == 0
     assert stats["batched"]["samples"] == length
-    return stats["batched"]
+    assert stats["batched_serial"]["components"] == stats["batched_serial"]["batches"]      # one walk per batch
+    assert stats["batched"]["components"] >= stats["batched"]["batches"]
+    return stats["batched_serial"], stats["batched"]
 
 
 @pytest.mark.parametrize("kind", [1, 2, 3, 4])
@@ -454,16 +459,18 @@ def test_lvq_exact_batches_stop_conditions(eng, E, oracle, kind, shape):
     kw = {"winlen": 0.3} if kind >= 3 else {}
     if kind == 4:
         kw["epsilon"] = 0.15
-    st = _lvq_both_engines(eng, E, oracle, kind, codes, clab, x, lab, length, 0.08, **kw)
+    st, stc = _lvq_both_engines(eng, E, oracle, kind, codes, clab, x, lab, length, 0.08, **kw)
     assert 1 <= st["batches"] <= length
     if shape == "one_cluster" and kind <= 2:
         assert st["stop_list"] > 0              # the case was built to exhaust candidate lists
     if shape == "wide_rows" and kind <= 2:
-        assert st["stop_cache"] > 0             # ... and this one to fill the 32-slot cache
+        assert st["stop_cache"] > 0             # ... and this one to fill the 32-slot cache (serial walk)
     if shape == "tiny_codebook":
         assert st["stop_list"] == 0             # all rows are listed: nothing can be missed
+        assert stc["components"] == stc["batches"]      # lists shorter than 8 rows: everything interacts
     if shape == "many_codes":
         assert st["batches"] <= length // 20    # the speculation has to pay off somewhere
+        assert stc["components"] > 4 * stc["batches"] and stc["batches"] <= st["batches"]   # 20 clusters walk side by side
 
 
 # --------------------------------------------------------------------------- error behaviour

@@ -39,8 +39,10 @@ def main():
         s1 = eng.lvq_stats()
         nb = s1["batches"] - s0["batches"]
         if nb:
-            print("   exact batches: %d (%.1f samples each; %d ended by the candidate list, %d by the cache); kernels ms: %s"
+            print("   exact batches: %d (%.1f samples each; %d ended by the candidate list, %d by the cache; %.1f independent components "
+                  "per batch, longest walk %.1f samples); kernels ms: %s"
                   % (nb, iters / nb, s1["stop_list"] - s0["stop_list"], s1["stop_cache"] - s0["stop_cache"],
+                     (s1["components"] - s0["components"]) / nb, (s1["largest"] - s0["largest"]) / nb,
                      {k: round(v[1], 1) for k, v in eng.timing_table().items() if v[0]}))
             print("   in-order kernel, us per sample by phase (inputs, distances, decision, correction):",
                   [round((a - b) / iters, 2) for a, b in zip(s1["phase_us"], s0["phase_us"])])
