@@ -228,6 +228,37 @@ int  somhip_som_batch_update(somhip_codebook *cb, somhip_dataset *ds, const somh
  * smallest keys per sample: that is find_winner_knn (lvq_pak.c:152-221) over the whole codebook. */
 int  somhip_batch_topk_keys(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
                             int knn, int tie, uint64_t *dev_keys);
+/* The lists of all shards, all-gathered into dev_gathered[n_shards][count][knn] -> dev_keys[count][knn], the knn
+ * smallest keys per sample, ascending: exactly the merge the comment above describes, on the device. */
+int  somhip_merge_topk_keys(somhip_engine *e, const uint64_t *dev_gathered, int n_shards, int64_t count, int knn,
+                            uint64_t *dev_keys);
+
+/* ---- lvq1/olvq1/lvq2/lvq3_training (lvq_rout.c:498-916) over a ROW-SHARDED codebook -----------------------------
+ * Every rank holds rows [row_offset, row_offset + n_rows) of the codebook (with their labels; OLVQ1: their rates,
+ * somhip_lvq_rates_upload) and sees the same data.  One batch of count <= 1024 iterations is three calls, the
+ * host's two collectives between them; the result is the reference's online result bit for bit, as with
+ * somhip_lvq_train:
+ *   1. somhip_batch_topk_keys(knn 8, tie = KNN for LVQ2/LVQ3 else FIRST)   this shard's 8 nearest rows per sample
+ *        host: all-gather the lists, somhip_merge_topk_keys                 -> the frozen global top 8 (every rank)
+ *   2. somhip_lvq_batch_candidates   labels / OLVQ1 rates of the 8 listed rows and tile copies of the `xrows`
+ *        nearest ones, filled in for the rows this shard owns, zero elsewhere:
+ *          dev_lab[count][8] int32, dev_ta[count][8] float (OLVQ1; else may be NULL),
+ *          dev_rows[count][xrows][4 * ceil(dim / 4)] float
+ *        host: all-reduce(SUM) of the three buffers as 32-bit INTEGERS (exact: every other rank adds 0)
+ *   3. somhip_lvq_batch_apply   every rank walks the batch (kernels/lvq_batch.hpp: the walk is deterministic, so
+ *        all ranks take the same decisions) and commits the corrected rows it owns.  *consumed <= count iterations
+ *        were applied -- the same number on every rank; the next batch starts there.  A winner beyond the `xrows`
+ *        exchanged rows ends the batch early (a larger xrows trades exchange volume for longer batches; 8 = never).
+ * trace_index / trace_diff: as somhip_lvq_train, for the consumed iterations. */
+int  somhip_lvq_rates_upload(somhip_codebook *cb, const float *talpha);     /* [n_rows] local rows, lvq_rout.c:614-627 */
+int  somhip_lvq_rates_download(somhip_codebook *cb, float *talpha);
+int  somhip_lvq_batch_candidates(somhip_codebook *cb, int64_t count, int kind, const uint64_t *dev_keys, int xrows,
+                                 int32_t *dev_lab, float *dev_ta, float *dev_rows);
+int  somhip_lvq_batch_apply(somhip_codebook *cb, somhip_dataset *ds, const somhip_lvq_params *p,
+                            int64_t batch_start_iter, int64_t count, int64_t data_first, const uint64_t *dev_keys,
+                            const int32_t *dev_lab, const float *dev_ta, const float *dev_rows, int xrows,
+                            int64_t *consumed, int32_t *trace_index, float *trace_diff);
+
 /* device scratch helpers for hosts without their own allocator */
 int  somhip_device_alloc(somhip_engine *e, int64_t bytes, void **dev_ptr);
 int  somhip_device_free(somhip_engine *e, void *dev_ptr);

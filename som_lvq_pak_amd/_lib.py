@@ -70,6 +70,13 @@ SIGNATURES = {
                                    c_float_p]),
     "somhip_batch_winner_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "somhip_batch_topk_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "somhip_merge_topk_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
+    "somhip_lvq_rates_upload": (C.c_int, [C.c_void_p, c_float_p]),
+    "somhip_lvq_rates_download": (C.c_int, [C.c_void_p, c_float_p]),
+    "somhip_lvq_batch_candidates": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]),
+    "somhip_lvq_batch_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(LvqParams), C.c_int64, C.c_int64, C.c_int64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_i64_p, c_i32_p, c_float_p]),
     "somhip_som_batch_update": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SomParams), C.c_int64,
                                           C.c_int64, C.c_int64, C.c_void_p]),
     "somhip_device_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),

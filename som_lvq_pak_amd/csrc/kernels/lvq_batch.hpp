@@ -617,6 +617,30 @@ __global__ void k_lvq_cand_meta(CbView cb, const uint64_t *__restrict__ cand, in
   if (cand_ta) cand_ta[e] = ta;
 }
 
+// X2 merge: gathered[g][count][K] = every shard's K best keys per sample -> the K smallest per sample
+// (keys are unique: tag = global row or its complement), ascending, missing entries all-ones.  One thread per sample.
+template <int K>
+__global__ void k_merge_shard_topk(const uint64_t *__restrict__ gathered, int nshards, int64_t count, uint64_t *__restrict__ out) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  uint64_t top[K];
+#pragma unroll
+  for (int t = 0; t < K; t++) top[t] = KEY_NONE;
+  for (int g = 0; g < nshards; g++)
+    for (int t = 0; t < K; t++) {
+      uint64_t v = gathered[(static_cast<int64_t>(g) * count + j) * K + t];
+      if (v >= top[K - 1]) break;                       // each shard's list is ascending
+#pragma unroll
+      for (int u = 0; u < K; u++) {                     // sorted insertion
+        const uint64_t lo = top[u] < v ? top[u] : v;
+        v = top[u] < v ? v : top[u];
+        top[u] = lo;
+      }
+    }
+#pragma unroll
+  for (int t = 0; t < K; t++) out[j * K + t] = top[t];
+}
+
 // tile-form copies of the xc nearest frozen candidates of every sample (rows of this shard; others stay 0)
 __global__ __launch_bounds__(256) void k_lvq_cand_rows(CbView cb, const uint64_t *__restrict__ cand, int count, int xc, int knn,
                                                        float4 *__restrict__ cand_rows) {

@@ -1,4 +1,4 @@
-"""Row-sharded SOM training step across ranks (one process per GPU, torch.distributed).
+"""Row-sharded SOM and LVQ training across ranks (one process per GPU, torch.distributed).
 
 The codebook is split into contiguous row blocks; every rank sees the same batch.  Per batch:
   1. each rank finds the best row of ITS shard for every sample   -> packed keys [B]
@@ -207,3 +207,155 @@ class GpuShard:
             yield
             torch.cuda.current_stream().synchronize()
         return host_synced()
+
+
+
+# ------------------------------------------------------------------------------------------------
+# lvq1 / olvq1 / lvq2 / lvq3_training (reference lvq_rout.c:498-916) over a row-sharded codebook
+# ------------------------------------------------------------------------------------------------
+def allgather_tensor(t, group=None):
+    """[...] -> [world, ...] (a copy with one leading axis in a single process)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return t.unsqueeze(0).contiguous()
+    staged = t.is_cuda and dist.get_backend(group) == "gloo"
+    src = (t.cpu() if staged else t).contiguous()
+    parts = [torch.empty_like(src) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, src, group=group)
+    out = torch.stack(parts, dim=0)
+    return out.to(t.device) if staged else out
+
+
+def allreduce_sum_bits(t, group=None):
+    """In-place SUM of a buffer seen as 32-bit integers: exact when, for every element, all ranks but one hold 0
+    (a float sum would turn -0.0 into +0.0)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return t
+    v = t.view(torch.int32)
+    if v.is_cuda and dist.get_backend(group) == "gloo":
+        host = v.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        v.copy_(host)
+    else:
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class ShardedLvq:
+    """The LVQ loops over a row-sharded codebook, exact (bit-identical to the reference's online loop).
+
+    Per batch of <= 1024 iterations (include/somhip.h, "lvq*_training over a ROW-SHARDED codebook"):
+      1. every rank: the 8 nearest rows of ITS shard for every sample        -> all-gather, keep the 8 smallest
+      2. every rank: labels / rates / rows of the listed candidates it owns   -> all-reduce(SUM) as integers
+      3. every rank walks the batch (deterministic: all take the same decisions) and commits the rows it owns
+    `shard` provides topk_keys / merge / candidates / apply (GpuLvqShard on an MI355X; a checker-backed one in
+    the CPU tests).  xrows: how many of the 8 candidates' rows are exchanged (a winner beyond them ends the batch)."""
+
+    def __init__(self, shard, kind, n_data, xrows=4, max_batch=1024, group=None):
+        self.shard, self.kind, self.n_data, self.xrows, self.group = shard, kind, n_data, xrows, group
+        self.max_batch = max_batch
+        self.knn = 2 if kind in (3, 4) else 1
+        self.batches = 0
+
+    def batch(self, it0, data_first, count):
+        keys = self.shard.merge(allgather_tensor(self.shard.topk_keys(data_first, count), self.group), count)
+        lab, ta, rows = self.shard.candidates(keys, count, self.xrows)
+        with self.shard.collective_scope():
+            allreduce_sum_bits(lab, self.group)
+            if ta is not None:
+                allreduce_sum_bits(ta, self.group)
+            allreduce_sum_bits(rows, self.group)
+        self.batches += 1
+        return self.shard.apply(it0, count, data_first, keys, lab, ta, rows, self.xrows)
+
+    def train(self, length, start_iter=0, count=None, data_first=None):
+        """iterations [start_iter, start_iter + count) of a schedule of `length`; returns (trace_index, trace_diff)"""
+        count = length - start_iter if count is None else count
+        data_first = start_iter % self.n_data if data_first is None else data_first
+        ti, td = [], []
+        off, B = 0, min(256, self.max_batch)
+        while off < count:
+            c = min(B, count - off)
+            done, i, d = self.batch(start_iter + off, (data_first + off) % self.n_data, c)
+            assert 0 < done <= c
+            ti.append(i)
+            td.append(d)
+            off += done
+            B = min(self.max_batch, 2 * B) if done == c else min(self.max_batch, max(32, done + done // 4 + 8))
+        return np.concatenate(ti), np.concatenate(td)
+
+
+class GpuLvqShard:
+    """The local half on an MI355X, through the C ABI (somhip_batch_topk_keys, somhip_merge_topk_keys,
+    somhip_lvq_batch_candidates, somhip_lvq_batch_apply).  All exchanged buffers are torch tensors on the GPU."""
+
+    def __init__(self, engine, codebook, dataset, params_factory, kind):
+        import torch
+        self.e, self.cb, self.ds, self.kind = engine, codebook, dataset, kind
+        self.params_factory = params_factory          # -> LvqParams (length, alpha, ... ; the per-batch fields are ignored)
+        self.knn = 2 if kind in (3, 4) else 1
+        self.dev = torch.device("cuda", engine.device)
+        self.d4 = (codebook.dim + 3) // 4
+
+    def topk_keys(self, first, count):
+        import ctypes as C
+        import torch
+        from ._lib import check
+        keys = torch.empty((count, 8), dtype=torch.int64, device=self.dev)
+        check(self.e.lib.somhip_batch_topk_keys(self.cb.h, self.ds.h, first, count, 8, 1 if self.knn == 2 else 0,
+                                                C.c_void_p(keys.data_ptr())))
+        self.e.sync()
+        return keys
+
+    def merge(self, gathered, count):
+        import ctypes as C
+        import torch
+        from ._lib import check
+        gathered = gathered.contiguous()
+        out = torch.empty((count, 8), dtype=torch.int64, device=self.dev)
+        check(self.e.lib.somhip_merge_topk_keys(self.e.h, C.c_void_p(gathered.data_ptr()), gathered.shape[0], count, 8,
+                                                C.c_void_p(out.data_ptr())))
+        self.e.sync()
+        return out
+
+    def candidates(self, keys, count, xrows):
+        import ctypes as C
+        import torch
+        from ._lib import check
+        lab = torch.empty((count, 8), dtype=torch.int32, device=self.dev)
+        ta = torch.empty((count, 8), dtype=torch.float32, device=self.dev) if self.kind == 2 else None
+        rows = torch.empty((count, xrows, 4 * self.d4), dtype=torch.float32, device=self.dev)
+        check(self.e.lib.somhip_lvq_batch_candidates(self.cb.h, count, self.kind, C.c_void_p(keys.data_ptr()), xrows,
+                                                     C.c_void_p(lab.data_ptr()), C.c_void_p(ta.data_ptr()) if ta is not None else None,
+                                                     C.c_void_p(rows.data_ptr())))
+        self.e.sync()
+        return lab, ta, rows
+
+    def apply(self, it0, count, first, keys, lab, ta, rows, xrows):
+        import ctypes as C
+        from . import _lib
+        from ._lib import check
+        p = self.params_factory()
+        done = C.c_int64(0)
+        ti = np.empty(count * self.knn, dtype=np.int32)
+        td = np.empty(count * self.knn, dtype=np.float32)
+        check(self.e.lib.somhip_lvq_batch_apply(self.cb.h, self.ds.h, C.byref(p), it0, count, first, C.c_void_p(keys.data_ptr()),
+                                                C.c_void_p(lab.data_ptr()), C.c_void_p(ta.data_ptr()) if ta is not None else None,
+                                                C.c_void_p(rows.data_ptr()), xrows, C.byref(done),
+                                                ti.ctypes.data_as(_lib.c_i32_p), td.ctypes.data_as(_lib.c_float_p)))
+        n = done.value
+        return n, ti[:n * self.knn], td[:n * self.knn]
+
+    def collective_scope(self):
+        """host-synchronous calls on both sides (each C call returns with its work complete): torch's own stream"""
+        import contextlib
+        import torch
+
+        @contextlib.contextmanager
+        def synced():
+            yield
+            torch.cuda.current_stream().synchronize()
+        return synced()

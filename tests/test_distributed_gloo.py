@@ -62,6 +62,118 @@ class CheckerShard:
         return contextlib.nullcontext()
 
 
+class CheckerLvqShard:
+    """topk_keys / merge / candidates / apply of sharded.ShardedLvq for one shard, on the CPU checker.  Serves only ITS
+    rows to the exchange; for `apply` (replicated on every rank in production) it keeps a private replica of the whole
+    codebook, checks that the exchanged candidate rows equal the replica's, and walks the batch one sample at a time."""
+
+    def __init__(self, orc, codes, clab, r0, r1, data, dlab, kind, length, alpha, winlen=0.0, epsilon=0.0):
+        import torch
+        self.torch, self.orc = torch, orc
+        self.full, self.clab, self.r0, self.r1 = codes.copy(), clab, r0, r1
+        self.data, self.dlab, self.kind, self.length, self.alpha = data, dlab, kind, length, alpha
+        self.winlen, self.epsilon = winlen, epsilon
+        self.knn = 2 if kind in (3, 4) else 1
+        self.talpha = np.full(codes.shape[0], alpha, dtype=np.float32)
+        self.d4 = (codes.shape[1] + 3) // 4
+
+    def _keys(self, rows, base, x):
+        """every row's exact key for every sample, ascending (tag = global row, complemented for the k-NN tie rule)"""
+        n = rows.shape[0]
+        wi, wd, _ = self.orc.winners(rows, x, n, True)
+        tag = (wi + base).astype(np.uint64)
+        if self.knn == 2:
+            tag = (~tag) & np.uint64(0xFFFFFFFF)
+        keys = (wd.view(np.uint32).astype(np.uint64) << np.uint64(32)) | tag
+        return np.sort(keys, axis=1)
+
+    def _samples(self, first, count):
+        return self.data[[(first + j) % self.data.shape[0] for j in range(count)]]
+
+    def topk_keys(self, first, count):
+        keys = self._keys(self.full[self.r0:self.r1], self.r0, self._samples(first, count))
+        out = np.full((count, 8), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+        k = min(8, keys.shape[1])
+        out[:, :k] = keys[:, :k]
+        return self.torch.from_numpy(out.view(np.int64).copy())
+
+    def merge(self, gathered, count):
+        g = gathered.numpy().view(np.uint64)                       # [world, count, 8]
+        allk = np.sort(np.concatenate(list(g), axis=1), axis=1)[:, :8]
+        return self.torch.from_numpy(np.ascontiguousarray(allk).view(np.int64).copy())
+
+    def _rows_of(self, keys):
+        k = keys.numpy().view(np.uint64)
+        none = k == np.uint64(0xFFFFFFFFFFFFFFFF)
+        tag = k & np.uint64(0xFFFFFFFF)
+        row = ((~tag) & np.uint64(0xFFFFFFFF) if self.knn == 2 else tag).astype(np.int64)
+        row[none] = -1
+        return row
+
+    def candidates(self, keys, count, xrows):
+        row = self._rows_of(keys)
+        mine = (row >= self.r0) & (row < self.r1)
+        lab = np.where(mine, self.clab[np.clip(row, 0, None)], 0).astype(np.int32)
+        ta = np.where(mine, self.talpha[np.clip(row, 0, None)], 0).astype(np.float32) if self.kind == 2 else None
+        rows = np.zeros((count, xrows, 4 * self.d4), dtype=np.float32)
+        d = self.full.shape[1]
+        for j in range(count):
+            for c in range(xrows):
+                if mine[j, c]:
+                    rows[j, c, :d] = self.full[row[j, c]]
+        t = self.torch.from_numpy
+        return t(lab), (t(ta) if ta is not None else None), t(rows)
+
+    def apply(self, it0, count, first, keys, lab, ta, rows, xrows):
+        row = self._rows_of(keys)
+        d = self.full.shape[1]
+        got_rows, got_lab = rows.numpy(), lab.numpy()
+        for j in range(count):                                  # the exchange delivered every listed row it promised
+            for c in range(8):
+                if row[j, c] >= 0:
+                    assert got_lab[j, c] == self.clab[row[j, c]]
+                    if c < xrows:
+                        assert np.array_equal(got_rows[j, c, :d].view(np.uint32), self.full[row[j, c]].view(np.uint32))
+        ti = np.zeros(count * self.knn, dtype=np.int32)
+        td = np.zeros(count * self.knn, dtype=np.float32)
+        orc = self.orc
+        ratio = np.float32((np.float32(1) - np.float32(self.winlen)) / (np.float32(1) + np.float32(self.winlen)))
+        for j in range(count):                                  # lvq_rout.c:542-555, 650-673, 855-896, one sample at a time
+            r = (first + j) % self.data.shape[0]
+            x, xl = self.data[r], self.dlab[r]
+            wi, wd, _ = orc.winners(self.full, x[None, :], self.knn, self.knn == 2)
+            ti[j * self.knn:(j + 1) * self.knn], td[j * self.knn:(j + 1) * self.knn] = wi[0], wd[0]
+            a = orc.alpha(1, it0 + j, self.length, self.alpha)
+            b = int(wi[0, 0])
+            if self.kind == 1:
+                self.full[b] = orc.adapt_vector(self.full[b], x, a if self.clab[b] == xl else -a)
+            elif self.kind == 2:
+                t = self.talpha[b]
+                if self.clab[b] == xl:
+                    self.full[b] = orc.adapt_vector(self.full[b], x, t)
+                    self.talpha[b] = np.float32(t / np.float32(1 + t))
+                else:
+                    self.full[b] = orc.adapt_vector(self.full[b], x, -t)
+                    self.talpha[b] = min(np.float32(t / np.float32(1 - t)), np.float32(self.alpha))
+            else:
+                nb = int(wi[0, 1])
+                if self.clab[b] != self.clab[nb]:
+                    if (self.clab[b] == xl or self.clab[nb] == xl) and np.float32(wd[0, 0] / wd[0, 1]) > ratio:
+                        if self.clab[nb] == xl:
+                            b, nb = nb, b
+                        self.full[b] = orc.adapt_vector(self.full[b], x, a)
+                        self.full[nb] = orc.adapt_vector(self.full[nb], x, -a)
+                elif self.kind == 4 and self.clab[b] == xl:
+                    ae = np.float32(np.float32(a) * np.float32(self.epsilon))
+                    self.full[b] = orc.adapt_vector(self.full[b], x, ae)
+                    self.full[nb] = orc.adapt_vector(self.full[nb], x, ae)
+        return count, ti, td
+
+    def collective_scope(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -109,6 +221,20 @@ def _worker(rank, world, port, q):
         fi, fd, _ = orc.winners(codes, x, 2, True)
         if rank == 0:
             out["knn"] = (bool(np.array_equal(gi, fi)), bool(np.array_equal(gd.view(np.uint32), fd.view(np.uint32))))
+        # the LVQ loops over a row-sharded codebook: all-gather of candidate lists, integer all-reduce of their rows
+        x, lab = synth(77, 160, 9, k=4)
+        pick = np.random.RandomState(3).choice(160, 37, replace=False)
+        codes, clab = x[pick].copy(), lab[pick].copy()
+        r0, r1 = sharded.shard_rows(37, world, rank)
+        for kind, kw in ((1, {}), (2, {}), (4, {"winlen": 0.3, "epsilon": 0.2})):
+            sh = CheckerLvqShard(orc, codes, clab, r0, r1, x, lab, kind, 300, 0.07, **kw)
+            lv = sharded.ShardedLvq(sh, kind, x.shape[0], xrows=3, max_batch=64)
+            ti, td = lv.train(300)
+            got = sharded.gather_codebook(sh.full[r0:r1], np.arange(r0, r1), 37)
+            if rank == 0:
+                wc, wt, wi, wd = orc.lvq_train(kind, codes, clab, x, lab, 300, 0.07, **kw)
+                out["lvq%d" % kind] = (bool(np.array_equal(got.view(np.uint32), wc.view(np.uint32))), bool(np.array_equal(ti, wi)),
+                                       bool(np.array_equal(td.view(np.uint32), wd.view(np.uint32))), lv.batches)
         # the all-ones "no winner" key must lose a signed MIN
         k = torch.tensor([-1 if rank == 0 else 5, 7 + rank], dtype=torch.int64)
         sharded.allreduce_min_keys(k)
@@ -136,6 +262,9 @@ def test_sharded_training_world2_gloo():
     assert out[2] == (True, True)          # interleaved patches
     assert out["none_key"] == [5, 7]
     assert out["knn"] == (True, True)
+    for kind in (1, 2, 4):
+        assert out["lvq%d" % kind][:3] == (True, True, True), kind
+        assert out["lvq%d" % kind][3] >= 5                       # 300 iterations in batches of at most 64
 
 
 def test_shard_rows_and_keys():

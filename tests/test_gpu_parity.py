@@ -854,3 +854,111 @@ def test_python_mirrors_survive_engine_close_first(E):
     e2.lib.somhip_dataset_destroy(ds.h)
     cb.h = ds.h = e2.h = None
     e2._children = []
+
+
+# --------------------------------------------------------------------------- LVQ over a row-sharded codebook
+_LVQ_SHARDED_CHILD = r'''
+import os, sys, ctypes as C
+import numpy as np, torch
+torch.cuda.set_device(0); torch.zeros(1, device="cuda")        # torch's HIP runtime first, then the engine's
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from conftest import synth
+from oracle import Oracle
+from som_lvq_pak_amd import engine as E, sharded
+from som_lvq_pak_amd._lib import LvqParams
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+class LocalLvqGroup:
+    """S shards of one codebook held in ONE process: the shard object sharded.ShardedLvq drives, with the two
+    collectives done by hand (stacking for the all-gather, an integer sum for the all-reduce) -- what N ranks do
+    over RCCL, on one GPU, so that the real kernels of every step are exercised."""
+
+    def __init__(self, eng, shards, kind, mk_params):
+        self.parts = [sharded.GpuLvqShard(eng, cb, ds, mk_params, kind) for cb, ds in shards]
+
+    def topk_keys(self, first, count):
+        return torch.stack([p.topk_keys(first, count) for p in self.parts], dim=0)      # already "gathered"
+
+    def merge(self, gathered, count):
+        g = gathered[0] if gathered.dim() == 4 else gathered                            # allgather_tensor adds an axis
+        outs = [p.merge(g, count) for p in self.parts]
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        return outs[0]
+
+    def candidates(self, keys, count, xrows):
+        got = [p.candidates(keys, count, xrows) for p in self.parts]
+        lab = sum(g[0].view(torch.int32) for g in got)
+        ta = None if got[0][1] is None else sum(g[1].view(torch.int32) for g in got).view(torch.float32)
+        rows = sum(g[2].view(torch.int32) for g in got).view(torch.float32)
+        return lab, ta, rows
+
+    def apply(self, it0, count, first, keys, lab, ta, rows, xrows):
+        res = [p.apply(it0, count, first, keys, lab, ta, rows, xrows) for p in self.parts]
+        assert all(r[0] == res[0][0] for r in res)                                      # every rank consumed the same
+        assert all(np.array_equal(r[1], res[0][1]) and np.array_equal(bits(r[2]), bits(res[0][2])) for r in res)
+        return res[0]
+
+    def collective_scope(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+
+orc, eng = Oracle(), E.Engine(0)
+ok = True
+for kind in (1, 2, 3, 4):
+    n, d, m, length = 900, 50, 1500, 2500
+    x, lab = synth(300 + kind, m, d, k=12, spread=2.5)
+    rs = np.random.RandomState(kind)
+    pick = rs.randint(0, m, n)
+    codes = (x[pick] + 0.05 * rs.randn(n, d)).astype(np.float32)
+    clab = lab[pick].copy()
+    kw = {"winlen": 0.3} if kind >= 3 else {}
+    if kind == 4:
+        kw["epsilon"] = 0.15
+    oc, ol, oi, od = orc.lvq_train(kind, codes, clab, x, lab, length, 0.06, **kw)
+    cuts = [0, 260, 700, n]
+    for xrows in (2, 8):
+        ds = E.Dataset(eng, x, labels=lab)
+        shards = []
+        for a, b in zip(cuts, cuts[1:]):
+            cb = E.Codebook(eng, codes[a:b], labels=clab[a:b], row_offset=a, n_global=n)
+            if kind == 2:
+                ta0 = np.full(b - a, 0.06, dtype=np.float32)
+                E.check(eng.lib.somhip_lvq_rates_upload(cb.h, ta0.ctypes.data_as(C.POINTER(C.c_float))))
+            shards.append((cb, ds))
+        mk = lambda: LvqParams(kind, length, 0.06, 1, kw.get("winlen", 0.0), kw.get("epsilon", 0.0), 0, 0, 0)
+        lv = sharded.ShardedLvq(LocalLvqGroup(eng, shards, kind, mk), kind, m, xrows=xrows, max_batch=512)
+        ti, td = lv.train(length)
+        got = np.concatenate([cb.download() for cb, _ in shards])
+        good = np.array_equal(ti, oi) and np.array_equal(bits(td), bits(od)) and np.array_equal(bits(got), bits(oc))
+        if kind == 2:
+            tal = []
+            for cb, _ in shards:
+                t = np.empty(cb.n, dtype=np.float32)
+                E.check(eng.lib.somhip_lvq_rates_download(cb.h, t.ctypes.data_as(C.POINTER(C.c_float))))
+                tal.append(t)
+            good = good and np.array_equal(bits(np.concatenate(tal)), bits(ol))
+        print("kind", kind, "xrows", xrows, "batches", lv.batches, "ok", good)
+        ok = ok and good
+        for cb, _ in shards:
+            cb.close()
+        ds.close()
+print("RESULT", ok)
+'''
+
+
+def test_lvq_row_sharded_equals_online():
+    """lvq1 / olvq1 / lvq2 / lvq3 over a codebook cut into three uneven row shards: per-shard top-8 -> merge ->
+    candidate rows by integer all-reduce -> replicated walk -> owners commit.  Winners, distances, codebook and
+    OLVQ1 rates must be the unsharded online result, bit for bit; with 2 exchanged rows (batches end early when a
+    deeper candidate wins) as with all 8.  In a child process: torch's HIP runtime has to come up before the engine's."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, "-c", _LVQ_SHARDED_CHILD % (ROOT, ROOT)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert "RESULT True" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
