@@ -123,6 +123,8 @@ int  somhip_dataset_wrap_device(somhip_engine *e, const float *dev_rows, int64_t
  * which also becomes the data set's labels.  No host copy, no PCIe: what the C4/C5-sized runs need. */
 int  somhip_dataset_generate(somhip_engine *e, uint64_t seed, int k_centres, int dim, int64_t first_row,
                              int64_t n_rows, int32_t *centres, somhip_dataset **out);
+/* rows [first, first + count) of the mirror back to the host (generated data sets: picking initial codes) */
+int  somhip_dataset_download_rows(somhip_dataset *ds, int64_t first, int64_t count, float *rows);
 void somhip_dataset_destroy(somhip_dataset *ds);
 
 /* ---- winner scans: WINNER_FUNCTION over a run of samples (lvq_pak.h:146) -----
@@ -183,8 +185,9 @@ int  somhip_lvq_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_lvq_
  * the on-chip row cache was full, out[4..7] = 100 MHz ticks the in-order kernel spent in
  * its phases (inputs, cached-row distances, decision, correction; summed over the components of a batch),
  * out[8] = independent components walked, out[9] = sum over the batches of the largest component's size
- * (the length of the longest serial walk) */
-int  somhip_lvq_stats(somhip_engine *e, uint64_t out[10]);
+ * (the length of the longest serial walk), out[10] = (sample, 64-row group) pairs the exact top-k re-rank behind the
+ * MFMA pre-filter evaluated, out[11] reserved */
+int  somhip_lvq_stats(somhip_engine *e, uint64_t out[12]);
 
 /* ---- lininit's data passes (find_eigenvectors, som_rout.c:211-289) ----------------
  * sum[i] / count[i]: fp32 sum and number of the unmasked values of component i over all rows in

@@ -62,6 +62,7 @@ SIGNATURES = {
                                           C.POINTER(C.c_void_p)]),
     "somhip_dataset_wrap_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                              C.POINTER(C.c_void_p)]),
+    "somhip_dataset_download_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_float_p]),
     "somhip_dataset_destroy": (None, [C.c_void_p]),
     "somhip_find_winners": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                       c_i32_p, c_float_p, c_i32_p]),

@@ -121,31 +121,48 @@ __global__ __launch_bounds__(256) void k_lvq_pair_adj(const float *__restrict__ 
                                                       uint32_t *__restrict__ adj) {
   const int tj = blockIdx.y, ti = blockIdx.x;
   if (ti > tj) return;
-  __shared__ float sa[64][33], sb[64][33];
+  // chunk-major LDS tiles [k / 4][row] of float4: a thread's 4 + 4 rows are 8 ds_read_b128 per 4 dims (192 flop)
+  __shared__ float4 sa[8][64], sb[8][64];
   __shared__ uint8_t sadj[64][65];
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const bool vec = (d & 3) == 0;
   float acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
     for (int b = 0; b < 4; b++) acc[a][b] = 0.0f;
   for (int k0 = 0; k0 < d; k0 += 32) {
-    for (int e = tid; e < 64 * 32; e += 256) {
-      const int r = e >> 5, k = e & 31;
-      const int ja = tj * 64 + r, ib = ti * 64 + r;
-      sa[r][k] = (ja < count && k0 + k < d) ? rows[((first + ja) % n_rows) * static_cast<int64_t>(d) + k0 + k] : 0.0f;
-      sb[r][k] = (ib < count && k0 + k < d) ? rows[((first + ib) % n_rows) * static_cast<int64_t>(d) + k0 + k] : 0.0f;
+    for (int e = tid; e < 64 * 8; e += 256) {                 // e -> (row, chunk of 4 dims); 8 consecutive chunks = 128 B of one row
+      const int r = e >> 3, q = e & 7;
+      const int ja = tj * 64 + r, ib = ti * 64 + r, k = k0 + 4 * q;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      if (k < d) {
+        const float *pa = rows + ((first + ja) % n_rows) * static_cast<int64_t>(d) + k;
+        const float *pb = rows + ((first + ib) % n_rows) * static_cast<int64_t>(d) + k;
+        if (vec) {
+          if (ja < count) va = *reinterpret_cast<const float4 *>(pa);
+          if (ib < count) vb = *reinterpret_cast<const float4 *>(pb);
+        } else {
+          float ta[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int u = 0; u < 4 && k + u < d; u++) { if (ja < count) ta[u] = pa[u]; if (ib < count) tb[u] = pb[u]; }
+          va = make_float4(ta[0], ta[1], ta[2], ta[3]); vb = make_float4(tb[0], tb[1], tb[2], tb[3]);
+        }
+      }
+      sa[q][r] = va; sb[q][r] = vb;
     }
     __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 32; k++) {
-      float va[4], vb[4];
 #pragma unroll
-      for (int a = 0; a < 4; a++) { va[a] = sa[ty * 4 + a][k]; vb[a] = sb[tx * 4 + a][k]; }
+    for (int q = 0; q < 8; q++) {
+      float4 va[4], vb[4];
+#pragma unroll
+      for (int a = 0; a < 4; a++) { va[a] = sa[q][ty * 4 + a]; vb[a] = sb[q][tx * 4 + a]; }
 #pragma unroll
       for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) { const float t = va[a] - vb[b]; acc[a][b] += t * t; }
+        for (int b = 0; b < 4; b++) {
+          const float t0 = va[a].x - vb[b].x, t1 = va[a].y - vb[b].y, t2 = va[a].z - vb[b].z, t3 = va[a].w - vb[b].w;
+          acc[a][b] += t0 * t0; acc[a][b] += t1 * t1; acc[a][b] += t2 * t2; acc[a][b] += t3 * t3;
+        }
     }
     __syncthreads();
   }

@@ -113,6 +113,8 @@ struct somhip_engine {
   uint64_t samples_searched = 0;
   uint64_t lvq_batches = 0, lvq_samples = 0;   // exact batched LVQ: rescans and samples
   uint64_t lvq_stop_list = 0, lvq_stop_cache = 0, lvq_cycles[4] = {0, 0, 0, 0};   // batches ended by an exhausted candidate list / a full cache
+  uint64_t topk_pairs = 0;                        // (sample, row group) pairs the exact top-k re-rank evaluated (64 rows each)
+  int64_t lvq_batch_hint = 256;                   // batch size the exact LVQ engine starts its next call with
   uint64_t lvq_components = 0, lvq_largest = 0;   // independent components walked, and the sum of the largest one's size per batch
   // ring of pinned host staging buffers for per-batch scalars (H2D without a host sync)
   void *pin_buf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -276,11 +278,11 @@ extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[6]) try {
   out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = e->samples_searched; out[4] = h[3]; out[5] = h[4];
   return 0;
 } ABI_CATCH(somhip_scan_stats)
-extern "C" int somhip_lvq_stats(somhip_engine *e, uint64_t out[10]) try {
+extern "C" int somhip_lvq_stats(somhip_engine *e, uint64_t out[12]) try {
   if (!e || !out) return fail("somhip_lvq_stats: null argument");
   out[0] = e->lvq_batches; out[1] = e->lvq_samples; out[2] = e->lvq_stop_list; out[3] = e->lvq_stop_cache;
   for (int k = 0; k < 4; k++) out[4 + k] = e->lvq_cycles[k];
-  out[8] = e->lvq_components; out[9] = e->lvq_largest;
+  out[8] = e->lvq_components; out[9] = e->lvq_largest; out[10] = e->topk_pairs; out[11] = 0;
   return 0;
 } ABI_CATCH(somhip_lvq_stats)
 extern "C" int somhip_timing_enable(somhip_engine *e, int on) try {
@@ -598,6 +600,17 @@ extern "C" int somhip_dataset_generate(somhip_engine *e, uint64_t seed, int k_ce
   *out = ds;
   return 0;
 } ABI_CATCH(somhip_dataset_generate)
+extern "C" int somhip_dataset_download_rows(somhip_dataset *ds, int64_t first, int64_t count, float *rows) try {
+  if (!ds || !rows) return fail("somhip_dataset_download_rows: null argument");
+  if (!ds->e) return fail("somhip_dataset_download_rows: the engine of this data set was destroyed");
+  if (first < 0 || count < 0 || first + count > ds->n) return fail("somhip_dataset_download_rows: rows [%lld,%lld) outside %lld",
+                                                                 (long long)first, (long long)(first + count), (long long)ds->n);
+  if (count == 0) return 0;
+  HIPCHK(hipSetDevice(ds->e->device));
+  HIPCHK(hipMemcpyAsync(rows, ds->d_rows + first * ds->d, sizeof(float) * (size_t)count * ds->d, hipMemcpyDeviceToHost, ds->e->stream));
+  HIPCHK(hipStreamSynchronize(ds->e->stream));
+  return 0;
+} ABI_CATCH(somhip_dataset_download_rows)
 static void dataset_release(somhip_dataset *ds) {
   if (ds->owns_rows && ds->d_rows) (void)hipFree((void *)ds->d_rows);
   if (ds->d_mask) (void)hipFree(ds->d_mask);

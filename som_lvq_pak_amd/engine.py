@@ -66,10 +66,11 @@ class Engine:
 
     def lvq_stats(self):
         """exact batched LVQ: codebook rescans (batches) and samples so far"""
-        out = (C.c_uint64 * 10)()
+        out = (C.c_uint64 * 12)()
         check(self.lib.somhip_lvq_stats(self.h, out))
         return {"batches": out[0], "samples": out[1], "stop_list": out[2], "stop_cache": out[3],
-                "phase_us": [out[4 + k] / 100.0 for k in range(4)], "components": out[8], "largest": out[9]}
+                "phase_us": [out[4 + k] / 100.0 for k in range(4)], "components": out[8], "largest": out[9],
+                "topk_pairs": out[10]}
 
     # --- timing table (HIP events on the engine's stream) ---
     def timing(self, on=True):
@@ -202,6 +203,12 @@ class Dataset:
                                                    C.byref(h)))
         self.h = h
         engine._adopt(self)
+
+    def rows(self, first, count):
+        """host copy of rows [first, first + count) (somhip_dataset_download_rows)"""
+        out = np.empty((count, self.dim), dtype=np.float32)
+        check(self.e.lib.somhip_dataset_download_rows(self.h, first, count, _p(out, _lib.c_float_p)))
+        return out
 
     def close(self):
         if self.h and self.e.h:

@@ -168,3 +168,81 @@ print("RESULT", ok)
 ''' % (ROOT, ROOT)
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert "RESULT True" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+# ------------------------------------------------------------------ BASELINE configs[2] and configs[4] at full size
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_c3_olvq1_full_size_against_reference_prefix():
+    """BASELINE.json configs[2]: OLVQ1, 10 000 codes x 256, 1 M labelled vectors of gen:k=100,dim=256,seed=2345, alpha0 0.3.
+    The REAL reference's olvq1_training ran the first 20 000 vectors here (tests/golden/make_golden.py --c3; OLVQ1 has no
+    global schedule, so that is the state of the full run after 20 000 iterations): winners, distances, codebook and the
+    "%g" text of the rates must match its hashes; then the run goes on to the full 1 M vectors."""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN
+    from som_lvq_pak_amd import engine as E
+    g = json.load(open(os.path.join(GOLDEN, "cli", "expected.json")))["c3_prefix"]
+    eng = E.Engine(0)
+    n = 1000000
+    ds = E.Dataset(eng, generate=(g["seed"], g["k"], g["dim"], 0, n))
+    head = ds.rows(0, g["head"])
+    cen = ds.centres
+    pick = np.concatenate([np.where(cen[:g["head"]] == c)[0][:g["codes_per_class"]] for c in range(g["k"])])
+    codes, clab = head[pick].copy(), cen[pick].astype(np.int32)
+    assert _sha(codes) == g["init_sha256"]                    # device stream == host stream, same picking rule
+    cb = E.Codebook(eng, codes, labels=clab)
+    tal, ti, td = E.lvq_train(cb, ds, E.OLVQ1, n, g["alpha"], count=g["prefix"])
+    assert _sha(ti.astype(np.int32)) == g["winners_sha256"]
+    assert _sha(td.astype(np.float32)) == g["diffs_sha256"]
+    assert _sha(cb.download()) == g["codes_sha256"]
+    assert hashlib.sha256(" ".join("%g" % v for v in tal).encode()).hexdigest() == g["rates_g_sha256"]
+    before = eng.lvq_stats()
+    tal, _, _ = E.lvq_train(cb, ds, E.OLVQ1, n, g["alpha"], start_iter=g["prefix"], talpha=tal, trace=False)
+    after = eng.lvq_stats()
+    assert after["samples"] - before["samples"] == n - g["prefix"]
+    assert (after["samples"] - before["samples"]) / (after["batches"] - before["batches"]) > 900     # ~1024 per rescan
+    dse = E.Dataset(eng, head[:20000])
+    wi, _, _ = E.find_winners(cb, dse)
+    assert (clab[wi[:, 0]] == cen[:20000]).mean() > 0.999
+    assert np.isfinite(tal).all() and (tal > 0).all() and (tal <= np.float32(g["alpha"])).all()
+    eng.close()
+
+
+def test_c5_shape_lvq3_batched_equals_online_kernel():
+    """BASELINE.json configs[4] shape on one GPU: LVQ3 (alpha 0.05, win 0.3, eps 0.1) on a 100 000 x 1024 codebook, stream
+    gen:k=1000,dim=1024,seed=4567.  No CPU can replay this; the exact batched engine (components walked side by side)
+    and the one-launch-per-iteration kernel are two independent implementations of the reference's online loop and must
+    give the same winners, distances and codebook bits.  (Reduced shapes against the oracle: test_gpu_parity.py.)"""
+    import os
+    from som_lvq_pak_amd import engine as E
+    eng = E.Engine(0)
+    ncodes, d, iters = 100000, 1024, 3000
+    ds = E.Dataset(eng, generate=(4567, 1000, d, 0, ncodes + 60000))
+    codes = ds.rows(0, ncodes)
+    clab = ds.centres[:ncodes].astype(np.int32)
+    res = {}
+    for mode in ("batched", "online"):
+        if mode == "online":
+            os.environ["SOMHIP_LVQ_ONLINE"] = "1"
+        try:
+            cb = E.Codebook(eng, codes, labels=clab)
+            s0 = eng.lvq_stats()
+            _, ti, td = E.lvq_train(cb, ds, E.LVQ3, 100000000, 0.05, winlen=0.3, epsilon=0.1, start_iter=0, count=iters,
+                                    data_first=ncodes)
+            s1 = eng.lvq_stats()
+            res[mode] = (ti, td, cb.download(), s1["components"] - s0["components"], s1["batches"] - s0["batches"])
+            cb.close()
+        finally:
+            os.environ.pop("SOMHIP_LVQ_ONLINE", None)
+    assert np.array_equal(res["batched"][0], res["online"][0])
+    assert np.array_equal(bits(res["batched"][1]), bits(res["online"][1]))
+    assert np.array_equal(bits(res["batched"][2]), bits(res["online"][2]))
+    assert not np.array_equal(bits(res["batched"][2]), bits(codes))          # something was learnt
+    assert res["batched"][3] > 50 * res["batched"][4]                        # hundreds of independent components per batch
+    assert res["online"][4] == 0
+    eng.close()
