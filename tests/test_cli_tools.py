@@ -463,3 +463,73 @@ def test_raw_fp32_reader_rejects_truncated_files(tools, tmp_path):
     assert open(tmp_path / "ok.txt").read().split("\n")[:3] == ["2", "1 2 a ", "x 4 b "]
     run("datconv", "-din", ok, "-dout", tmp_path / "ok2.f32")
     assert open(tmp_path / "ok2.f32", "rb").read().endswith(b"a \nb weight=3 \n")
+
+
+# ------------------------------------------------------------------ INTEGRATION.md, proven on the reference's own tools
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _glued(tool):
+    exe = os.path.join(REF, tool)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/%s not built (needs /root/reference at build time)" % tool)
+    return exe
+
+
+def _run_ref(exe, *args, env=None):
+    p = subprocess.run([exe] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, (exe, args, p.stderr)
+    return p
+
+
+def test_glued_reference_tools_keep_their_cpu_path(tmp_path):
+    """oracle/_ref/vsom_hip = the reference's unmodified vsom.o + library objects + som_lvq_pak_amd/host/glue/somhip_glue.c.
+    Without -selfuncs hip the glue must hand every call on to the reference's own loops: the reference's bytes."""
+    ex = EXPECTED["som"]["hexa_bubble"]
+    out = tmp_path / "o.cod"
+    _run_ref(_glued("vsom_hip"), "-din", os.path.join(DATA, "ex.dat"), "-cin", os.path.join(CLI, ex["init"]), "-cout", out,
+             "-rlen", ex["rlen"], "-alpha", ex["alpha"], "-radius", ex["radius"], "-v", 0)
+    assert md5(out) == ex["md5"]
+    p = _run_ref(_glued("qerror_hip"), "-din", os.path.join(DATA, "ex.dat"), "-cin", out, "-v", 0)
+    assert p.stdout == ex["qerror_stdout"]
+
+
+@pytest.mark.gpu
+def test_reference_tools_linked_with_the_glue(tmp_path):
+    """The reference's OWN host code (argument parsing, .dat/.cod I/O, labels, snapshots: vsom.o, qerror.o, lvqtrain.o and
+    the library objects compiled from /root/reference, unmodified) with `-selfuncs hip`: som_training / find_qerror /
+    lvq*_training go to the MI355X engine through the committed glue and must reproduce what the reference's CPU loops
+    wrote (tests/golden/cli/expected.json)."""
+    vsom, qerr, lvq = _glued("vsom_hip"), _glued("qerror_hip"), _glued("lvqtrain_hip")
+    d = os.path.join(DATA, "ex.dat")
+    for tag in ("hexa_bubble", "hexa_gaussian", "rect_bubble", "rect_gaussian"):
+        ex = EXPECTED["som"][tag]
+        out = tmp_path / (tag + ".cod")
+        p = _run_ref(vsom, "-din", d, "-cin", os.path.join(CLI, ex["init"]), "-cout", out, "-rlen", ex["rlen"], "-alpha", ex["alpha"],
+                     "-radius", ex["radius"], "-selfuncs", "hip", "-v", 0)
+        assert "not found" not in p.stderr                   # the name reached the glue, not the reference's "unknown row" warning
+        assert md5(out) == ex["md5"], tag
+        assert _run_ref(qerr, "-din", d, "-cin", out, "-selfuncs", "hip", "-v", 0).stdout == ex["qerror_stdout"], tag
+    out = tmp_path / "invt.cod"
+    _run_ref(vsom, "-din", d, "-cin", os.path.join(CLI, "som_init_hexa_bubble.cod"), "-cout", out, "-rlen", 5000, "-alpha", 0.05,
+             "-radius", 10, "-alpha_type", "inverse_t", "-rand", 7, "-selfuncs", "hip", "-v", 0)
+    ref = tmp_path / "invt_ref.cod"
+    _run_ref(vsom, "-din", d, "-cin", os.path.join(CLI, "som_init_hexa_bubble.cod"), "-cout", ref, "-rlen", 5000, "-alpha", 0.05,
+             "-radius", 10, "-alpha_type", "inverse_t", "-rand", 7, "-v", 0)
+    assert md5(out) == md5(ref)                              # -rand shuffle + inverse_t: engine == the same binary's CPU loop
+    # snapshots through the reference's own save_snapshot
+    ex = EXPECTED["buffer_snap"]["vsom_snap1"]
+    out = tmp_path / "snap.cod"
+    _run_ref(vsom, "-din", d, "-cin", os.path.join(CLI, ex["cin"]), "-cout", out, *ex["args"], "-snapfile",
+             str(tmp_path / "s1_%ld.snap"), "-selfuncs", "hip", "-v", 0)
+    assert md5(out) == ex["md5"]
+    for it, want in ex["snapshots"].items():
+        assert md5(tmp_path / ("s1_%s.snap" % it)) == want, it
+    # the LVQ loops (lvqtrain.c never reads -selfuncs: the row is selected through the environment)
+    for tag in ("lvq1", "lvq2", "lvq3", "olvq1", "olvq1_default"):
+        ex = EXPECTED["lvq"][tag]
+        out = tmp_path / (tag + ".cod")
+        _run_ref(lvq, "-type", ex["tool"], "-din", os.path.join(DATA, "ex1.dat"), "-cin", os.path.join(CLI, "lvq_init.cod"),
+                 "-cout", out, *ex["args"], "-v", 0, env={"SOMHIP_SELFUNCS": "hip"})
+        assert md5(out) == ex["md5"], tag
