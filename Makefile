@@ -16,8 +16,9 @@ all: lib oracle tools
 
 lib: $(LIB)
 KHDR      = $(CSRC)/kernels.hpp $(wildcard $(CSRC)/kernels/*.hpp) $(wildcard $(CSRC)/host_*.inc)
+# librccl.so is opened at run time by the first somhip_comm_create (host_comm.inc), never linked: -ldl only
 $(LIB): $(CSRC)/somhip.hip $(KHDR) $(CSRC)/schedule.hpp include/somhip.h Makefile
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/somhip.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/somhip.hip -ldl
 
 # device ISA of the kernels, for the no-FMA check (tests/test_build.py) and for reading
 isa: $(CSRC)/somhip.hip $(KHDR)

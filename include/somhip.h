@@ -43,6 +43,9 @@ typedef struct somhip_dataset somhip_dataset;     /* replaces the `data` entries
 const char *somhip_last_error(void);
 int somhip_version(void);
 
+/* GPUs visible to this process (a multi-GPU host: one process per GPU, rank r on device r % count) */
+int  somhip_device_count(int *count);
+
 /* ---- engine ---- */
 int  somhip_engine_create(int device, somhip_engine **out);
 /* Destroying an engine releases the device memory of every codebook / data set created on it; those handles
@@ -261,6 +264,25 @@ int  somhip_lvq_batch_apply(somhip_codebook *cb, somhip_dataset *ds, const somhi
                             int64_t batch_start_iter, int64_t count, int64_t data_first, const uint64_t *dev_keys,
                             const int32_t *dev_lab, const float *dev_ta, const float *dev_rows, int xrows,
                             int64_t *consumed, int32_t *trace_index, float *trace_diff);
+
+/* ---- collectives for a C host with one process per GPU ---------------------------------------------
+ * somhip_comm wraps an RCCL communicator (librccl.so is opened on first use, never linked): the all-reduce of packed
+ * winner keys is ncclAllReduce(ncclUint64, ncclMin) enqueued on the engine's own stream between
+ * somhip_batch_winner_keys and somhip_som_batch_update -- no host synchronisation in the step.
+ *   rank 0: somhip_comm_unique_id(id)  ->  the host hands the 128 bytes to the other ranks (pipe, file, MPI, ...)
+ *   all:    somhip_comm_create(engine, id, rank, world, &comm)
+ * somhip_comm_create_sockets: the same operations over host sockets in a star around rank 0 (fds: rank 0 passes the
+ * world-1 descriptors of ranks 1.., every other rank its one descriptor to rank 0) -- for rehearsals in which several
+ * ranks share a GPU (RCCL refuses duplicate devices); each operation then synchronises and stages through the host.
+ * allreduce_sum_u32 / allgather serve the LVQ exchange (candidate rows as integers; per-shard top-8 lists). */
+typedef struct somhip_comm somhip_comm;
+int  somhip_comm_unique_id(void *id128);
+int  somhip_comm_create(somhip_engine *e, const void *id128, int rank, int world, somhip_comm **out);
+int  somhip_comm_create_sockets(somhip_engine *e, int rank, int world, const int *fds, somhip_comm **out);
+int  somhip_comm_allreduce_min_keys(somhip_comm *c, uint64_t *dev_keys, int64_t count);
+int  somhip_comm_allreduce_sum_u32(somhip_comm *c, uint32_t *dev_words, int64_t count);
+int  somhip_comm_allgather(somhip_comm *c, const void *dev_send, void *dev_recv, int64_t bytes_per_rank);
+void somhip_comm_destroy(somhip_comm *c);
 
 /* device scratch helpers for hosts without their own allocator */
 int  somhip_device_alloc(somhip_engine *e, int64_t bytes, void **dev_ptr);

@@ -35,6 +35,7 @@ class LvqParams(C.Structure):
 SIGNATURES = {
     "somhip_last_error": (C.c_char_p, []),
     "somhip_version": (C.c_int, []),
+    "somhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "somhip_engine_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "somhip_engine_destroy": (None, [C.c_void_p]),
     "somhip_engine_stream": (C.c_void_p, [C.c_void_p]),
@@ -78,6 +79,13 @@ SIGNATURES = {
                                               C.c_void_p]),
     "somhip_lvq_batch_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(LvqParams), C.c_int64, C.c_int64, C.c_int64,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_i64_p, c_i32_p, c_float_p]),
+    "somhip_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "somhip_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "somhip_comm_create_sockets": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "somhip_comm_allreduce_min_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "somhip_comm_allreduce_sum_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "somhip_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "somhip_comm_destroy": (None, [C.c_void_p]),
     "somhip_som_batch_update": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SomParams), C.c_int64,
                                           C.c_int64, C.c_int64, C.c_void_p]),
     "somhip_device_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),

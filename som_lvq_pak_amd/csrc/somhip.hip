@@ -258,6 +258,14 @@ extern "C" void somhip_engine_destroy(somhip_engine *e) try {
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 } ABI_CATCH_VOID(somhip_engine_destroy)
+extern "C" int somhip_device_count(int *count) try {
+  if (!count) return fail("somhip_device_count: null argument");
+  int n = 0;
+  const hipError_t er = hipGetDeviceCount(&n);
+  if (er != hipSuccess) { *count = 0; return fail("somhip_device_count: %s", hipGetErrorString(er)); }
+  *count = n;
+  return 0;
+} ABI_CATCH(somhip_device_count)
 extern "C" void *somhip_engine_stream(somhip_engine *e) { return e ? (void *)e->stream : nullptr; }
 extern "C" int somhip_engine_sync(somhip_engine *e) try {
   if (!e) return fail("somhip_engine_sync: null engine");
@@ -633,3 +641,4 @@ extern "C" void somhip_dataset_destroy(somhip_dataset *ds) try {
 #include "host_scan.inc"
 #include "host_som.inc"
 #include "host_lvq.inc"
+#include "host_comm.inc"

@@ -37,6 +37,7 @@ int main(int argc, char **argv)
   if (noc <= 0 || xdim < 0) { fprintf(stderr, "Dimensions of map (%d %d) are incorrect\n", xdim, ydim); exit(1); }
 
   ifverbose(2) fprintf(stderr, "Input entries are read from file %s\n", in_data_file);
+  pak_gen_virtual_ok = 1;                              /* a gen: source stays on the device (bounding box / covariance passes) */
   struct entries *data = open_entries(in_data_file, 0, 1);
   if (!data) { fprintf(stderr, "Can't open data file '%s'\n", in_data_file); exit(1); }
   init_random((int)randomize);

@@ -53,6 +53,9 @@ struct entries {
   int labels_needed;
   long buffer;                  /* > 0 with random_order: -buffer N -rand, rows are presented buffer by buffer, */
   int random_order;             /*   each buffer reshuffled when it is (re)loaded (datafile.c:237-344)            */
+  int is_virtual;               /* a `gen:` source kept as its specification: rows exist only on the device */
+  unsigned long long gen_seed;  /*   (vsom / qerror / randinit / lininit, see pak_gen_virtual_ok); pak_materialize() */
+  int gen_k;                    /*   makes the host rows when something needs them after all                        */
   void *userdata;               /* device mirror handle (as lvq_pak.h:112) */
   unsigned long mirror_generation;   /* host-row generation the mirror was uploaded at (paklib.c, per-sample surface) */
 };
@@ -118,6 +121,12 @@ int save_entries_wcomments(struct entries *codes, const char *name, const char *
 #define save_entries(c, n) save_entries_wcomments((c), (n), NULL)
 /* raw fp32 side format ("#!somf32", paklib.c) -- open_entries reads it transparently, this writes it */
 int save_entries_f32(struct entries *c, const char *name);
+/* `-din gen:...` without a host copy: tools whose whole use of the data is epoch-level calls of the engine set this
+ * before open_entries(); the rows are then generated in HBM by somhip_dataset_generate when the mirror is made (a
+ * 10 M x 512 stream is 20 GB the host never allocates, parses or sends over PCIe).  Sources with labels=1, and any
+ * later need for host rows (-rand, -buffer), materialise as before. */
+extern int pak_gen_virtual_ok;
+int pak_materialize(struct entries *e);
 /* the seeded Gaussian-mixture stream behind `-din gen:k=..,dim=..,n=..,seed=..[,labels=1]` (paklib.c) */
 uint64_t pak_splitmix64(uint64_t x);
 float pak_gen_z(uint64_t seed, uint64_t counter);
@@ -176,5 +185,8 @@ void pak_train_cli(int argc, char **argv, struct pak_train_cli *o);
  * reshuffling when -buffer is smaller than the file (datafile.c:237-344) */
 void pak_apply_rand(struct entries *data, const char *rand_s, long buffer);
 void pak_shutdown(void);
+/* vsom -gpus G: one process per GPU, codebook sharded, RCCL all-reduce of the winner keys (paklib.c).  Must be called
+ * before this process has used a GPU; rank 0 runs after(teach, arg) (save the codebook) when training succeeded. */
+int som_training_multi(struct teach_params *teach, int gpus, int (*after)(struct teach_params *, void *), void *arg);
 
 #endif

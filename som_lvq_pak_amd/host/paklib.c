@@ -419,6 +419,24 @@ int pak_parse_gen(const char *spec, long *n, int *dim, int *k, uint64_t *seed, i
   if (*n <= 0 || *dim <= 0 || *dim > 32767 || *k <= 0) { fprintf(stderr, "gen: needs n=, dim= (and k > 0)\n"); return -1; }
   return 1;
 }
+int pak_gen_virtual_ok = 0;
+
+/* host rows of a virtual source (same stream, same bits as the device's) */
+int pak_materialize(struct entries *e)
+{
+  if (!e || !e->is_virtual) return 0;
+  const long n = e->num_entries;
+  const int dim = e->dimension;
+  e->points = malloc(sizeof(float) * (size_t)n * dim);
+  e->rows = calloc((size_t)n, sizeof(struct data_entry));
+  if (!e->points || !e->rows) { fprintf(stderr, "gen: out of memory for %ld x %d host rows\n", n, dim); return 1; }
+#pragma omp parallel for schedule(static)
+  for (long r = 0; r < n; r++) pak_gen_row(e->gen_seed, e->gen_k, dim, r, e->points + r * dim, NULL);
+  e->is_virtual = 0;
+  finish_entries(e, NULL, NULL, 0, 0);
+  return 0;
+}
+
 static struct entries *gen_entries(const char *spec)
 {
   long n; int dim, k, labels; uint64_t seed;
@@ -426,6 +444,10 @@ static struct entries *gen_entries(const char *spec)
   struct entries *e = calloc(1, sizeof *e);
   e->dimension = (short)dim;
   e->num_entries = n;
+  if (pak_gen_virtual_ok && !labels) {                 /* kept as a specification: the engine generates it in HBM */
+    e->is_virtual = 1; e->gen_seed = seed; e->gen_k = k;
+    return e;
+  }
   e->points = malloc(sizeof(float) * (size_t)n * dim);
   e->rows = calloc((size_t)n, sizeof(struct data_entry));
   int *centre = malloc(sizeof(int) * (size_t)n);
@@ -532,7 +554,7 @@ void close_entries(struct entries *e)
 {
   if (!e) return;
   if (e->userdata) somhip_codebook_destroy(e->userdata);     /* the per-sample surface's mirror (an orphan if the engine went first) */
-  for (long r = 0; r < e->num_entries; r++) free(e->rows[r].labels);
+  for (long r = 0; e->rows && r < e->num_entries; r++) free(e->rows[r].labels);   /* (a virtual gen: source has no rows) */
   free(e->rows); free(e->points); free(e->masks); free(e->fixed_xy); free(e->weights);
   free(e);
 }
@@ -720,16 +742,18 @@ void pak_apply_rand(struct entries *data, const char *rand_s, long buffer)
 {
   init_random((int)oatoi(rand_s, 0));
   if (!rand_s) return;
+  if (pak_materialize(data)) exit(1);                  /* a shuffle needs the rows on the host */
   if (buffer > 0 && buffer < data->num_entries) { data->buffer = buffer; data->random_order = 1; }   /* reshuffled per buffer */
   else randomize_entry_order(data);                                                               /* once, at load */
 }
 
 /* ------------------------------------------------------------------ the HIP back end */
 static somhip_engine *g_engine = NULL;
+static int g_device = 0;                               /* a rank of a multi-GPU run sets this before its first engine() */
 
 static somhip_engine *engine(void)
 {
-  if (!g_engine && somhip_engine_create(0, &g_engine)) {
+  if (!g_engine && somhip_engine_create(g_device, &g_engine)) {
     fprintf(stderr, "%s\n", somhip_last_error());
     return NULL;
   }
@@ -761,6 +785,16 @@ static somhip_dataset *mirror_data(struct entries *data, int with_labels)
   somhip_engine *en = engine();
   if (!en) return NULL;
   somhip_dataset *ds = NULL;
+  if (data->is_virtual) {
+    if (with_labels && pak_materialize(data)) return NULL;
+    if (data->is_virtual) {
+      if (somhip_dataset_generate(en, data->gen_seed, data->gen_k, data->dimension, 0, data->num_entries, NULL, &ds)) {
+        fprintf(stderr, "%s\n", somhip_last_error());
+        return NULL;
+      }
+      return ds;
+    }
+  }
   int32_t *lab = with_labels ? first_labels(data) : NULL;
   int rc = somhip_dataset_create(en, data->points, data->num_entries, data->dimension,
                                  (const uint8_t *)data->masks, lab, data->weights, data->fixed_xy, &ds);
@@ -963,6 +997,155 @@ done:
   return ret;
 }
 
+/* ------------------------------------------------------------------ som_training on G GPUs (vsom -gpus G)
+ * One process per GPU: the parent -- which has parsed the arguments and read the files, and has not
+ * touched a GPU -- forks G ranks; rank r takes device r % (visible GPUs), holds every G-th 8x8-unit patch of the map
+ * (somhip_codebook_create_interleaved; contiguous row blocks when a map side is not a multiple of 8) and the whole
+ * data set.  Per mini-batch: somhip_batch_winner_keys on its shard -> somhip_comm_allreduce_min_keys (RCCL
+ * ncclAllReduce(ncclUint64, ncclMin) on the engine's stream; the ranks get the communicator id from rank 0 over a
+ * socketpair the parent made) -> somhip_som_batch_update of its own rows.  The codebook comes together only at the end
+ * (X3), on rank 0, which returns it for saving.  When the ranks outnumber the GPUs (a rehearsal on one GPU: RCCL
+ * refuses duplicate devices) or SOMHIP_COMM=sockets, the keys travel over the same sockets instead. */
+#include <sys/socket.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+static int sock_write(int fd, const void *b, size_t n) { const char *p = b; while (n) { ssize_t k = write(fd, p, n); if (k <= 0) return 1; p += k; n -= (size_t)k; } return 0; }
+static int sock_read(int fd, void *b, size_t n) { char *p = b; while (n) { ssize_t k = read(fd, p, n); if (k <= 0) return 1; p += k; n -= (size_t)k; } return 0; }
+
+/* what one rank does; fds: rank 0 has world-1 descriptors (peer r at [r-1]), every other rank one (to rank 0) */
+static int som_training_rank(struct teach_params *teach, int rank, int world, int *fds)
+{
+  struct entries *codes = teach->codes, *data = teach->data;
+  const long n = codes->num_entries, dim = codes->dimension, L = teach->length;
+  const long B = teach->batch > 1 ? teach->batch : 4096;
+  int ndev = 0, rc = 1;
+  somhip_comm *comm = NULL;
+  somhip_codebook *cb = NULL;
+  somhip_dataset *ds = NULL;
+  void *dkeys = NULL;
+  int64_t *units = NULL, n_local = 0;
+  float *mine = NULL;
+  if (somhip_device_count(&ndev) || ndev < 1) { fprintf(stderr, "som_training: %s\n", somhip_last_error()); return 1; }
+  g_device = rank % ndev;
+  somhip_engine *en = engine();
+  if (!en) return 1;
+  const char *force = getenv("SOMHIP_COMM");
+  const int use_rccl = force ? strcmp(force, "rccl") == 0 : ndev >= world;
+  if (use_rccl) {
+    char id[128];
+    if (rank == 0) {
+      if (somhip_comm_unique_id(id)) goto hip_fail;
+      for (int r = 1; r < world; r++) if (sock_write(fds[r - 1], id, sizeof id)) goto done;
+    } else if (sock_read(fds[0], id, sizeof id)) goto done;
+    if (somhip_comm_create(en, id, rank, world, &comm)) goto hip_fail;
+  } else if (somhip_comm_create_sockets(en, rank, world, fds, &comm)) goto hip_fail;
+  ifverbose(2) fprintf(stderr, "rank %d/%d on GPU %d, keys by %s\n", rank, world, g_device, use_rccl ? "RCCL" : "host sockets");
+
+  /* this rank's units and rows */
+  const int interleaved = codes->xdim % 8 == 0 && codes->ydim % 8 == 0;
+  if (interleaved) {
+    if (somhip_shard_units(codes->xdim, codes->ydim, rank, world, NULL, &n_local)) goto hip_fail;
+    units = malloc(sizeof(int64_t) * (n_local + 1));
+    if (somhip_shard_units(codes->xdim, codes->ydim, rank, world, units, &n_local)) goto hip_fail;
+  } else {
+    const long per = (n + world - 1) / world, r0 = rank * per < n ? rank * per : n, r1 = r0 + per < n ? r0 + per : n;
+    n_local = r1 - r0;
+    units = malloc(sizeof(int64_t) * (n_local + 1));
+    for (long j = 0; j < n_local; j++) units[j] = r0 + j;
+  }
+  if (n_local <= 0) { fprintf(stderr, "som_training: more ranks (%d) than the map can be cut into\n", world); goto done; }
+  mine = malloc(sizeof(float) * n_local * dim);
+  for (long j = 0; j < n_local; j++) memcpy(mine + j * dim, codes->points + units[j] * dim, sizeof(float) * dim);
+  if (interleaved ? somhip_codebook_create_interleaved(en, mine, n_local, (int)dim, codes->topol, codes->neigh, codes->xdim, codes->ydim, rank, world, &cb)
+                  : somhip_codebook_create(en, mine, NULL, n_local, (int)dim, codes->topol, codes->neigh, codes->xdim, codes->ydim, units[0], n, &cb)) goto hip_fail;
+  if (!(ds = mirror_data(data, 0))) goto done;
+  if (somhip_device_alloc(en, 8 * B, &dkeys)) goto hip_fail;
+
+  somhip_som_params sp = { L, teach->alpha, teach->radius, teach->alpha_type, use_fixed_level, use_weights_level, B, 0, 0, 0 };
+  for (long it0 = 0; it0 < L;) {                       /* batches aligned to the schedule, as somhip_som_train cuts them */
+    const long c = B - it0 % B < L - it0 ? B - it0 % B : L - it0, first = it0 % data->num_entries;
+    if (somhip_batch_winner_keys(cb, ds, first, c, dkeys) || somhip_comm_allreduce_min_keys(comm, dkeys, c) ||
+        somhip_som_batch_update(cb, ds, &sp, it0, c, first, dkeys)) goto hip_fail;
+    it0 += c;
+  }
+  if (somhip_codebook_download(cb, mine)) goto hip_fail;
+  /* X3: every rank's rows, with their unit indices, to rank 0 */
+  if (rank == 0) {
+    for (long j = 0; j < n_local; j++) memcpy(codes->points + units[j] * dim, mine + j * dim, sizeof(float) * dim);
+    for (int r = 1; r < world; r++) {
+      int64_t cnt;
+      if (sock_read(fds[r - 1], &cnt, sizeof cnt)) goto done;
+      int64_t *u = malloc(sizeof(int64_t) * (cnt + 1));
+      float *rows = malloc(sizeof(float) * (cnt + 1) * dim);
+      const int bad = sock_read(fds[r - 1], u, sizeof(int64_t) * cnt) || sock_read(fds[r - 1], rows, sizeof(float) * cnt * dim);
+      for (long j = 0; !bad && j < cnt; j++) memcpy(codes->points + u[j] * dim, rows + j * dim, sizeof(float) * dim);
+      free(u); free(rows);
+      if (bad) goto done;
+    }
+  } else if (sock_write(fds[0], &n_local, sizeof n_local) || sock_write(fds[0], units, sizeof(int64_t) * n_local) ||
+             sock_write(fds[0], mine, sizeof(float) * n_local * dim)) goto done;
+  rc = 0;
+  goto done;
+hip_fail:
+  fprintf(stderr, "som_training (rank %d): %s\n", rank, somhip_last_error());
+done:
+  if (dkeys) somhip_device_free(en, dkeys);
+  if (ds) somhip_dataset_destroy(ds);
+  if (cb) somhip_codebook_destroy(cb);
+  if (comm) somhip_comm_destroy(comm);
+  free(units); free(mine);
+  return rc;
+}
+
+/* forks the ranks; rank 0 also runs after(teach, arg) -- the tool's "save the codebook" -- before it exits.
+ * Returns 0 when every rank succeeded. */
+int som_training_multi(struct teach_params *teach, int gpus, int (*after)(struct teach_params *, void *), void *arg)
+{
+  if (set_som_params(teach)) { fprintf(stderr, "som_training: can't set SOM parameters\n"); return 1; }
+  if (!teach->data || teach->data->num_entries <= 0) { fprintf(stderr, "som_training: can't get data\n"); return 1; }
+  if (teach->data->dimension != teach->codes->dimension) {
+    fprintf(stderr, "code dimension (%d) != data dimension (%d)\n", teach->codes->dimension, teach->data->dimension);
+    return 1;
+  }
+  if (teach->data->random_order && teach->data->buffer > 0 && teach->data->buffer < teach->data->num_entries) {
+    fprintf(stderr, "som_training: -buffer with -rand is not available with -gpus\n");
+    return 1;
+  }
+  if (teach->snapshot) fprintf(stderr, "som_training: snapshots are not written with -gpus\n");
+  if (g_engine) { fprintf(stderr, "som_training: the ranks must be started before this process uses a GPU\n"); return 1; }
+  int (*sv)[2] = malloc(sizeof(int[2]) * (gpus > 1 ? gpus - 1 : 1));
+  for (int r = 1; r < gpus; r++)
+    if (socketpair(AF_UNIX, SOCK_STREAM, 0, sv[r - 1])) { perror("socketpair"); free(sv); return 1; }
+  pid_t *pid = malloc(sizeof(pid_t) * gpus);
+  fflush(NULL);
+  for (int r = 0; r < gpus; r++) {
+    pid[r] = fork();
+    if (pid[r] < 0) { perror("fork"); free(sv); free(pid); return 1; }
+    if (pid[r] == 0) {
+      int *fds = malloc(sizeof(int) * (gpus > 1 ? gpus - 1 : 1));
+      for (int q = 1; q < gpus; q++) {
+        if (r == 0) { fds[q - 1] = sv[q - 1][0]; close(sv[q - 1][1]); }
+        else if (q == r) { fds[0] = sv[q - 1][1]; close(sv[q - 1][0]); }
+        else { close(sv[q - 1][0]); close(sv[q - 1][1]); }
+      }
+      int rc = som_training_rank(teach, r, gpus, fds);
+      if (rc == 0 && r == 0 && after) rc = after(teach, arg);
+      pak_shutdown();
+      fflush(NULL);
+      _exit(rc ? 1 : 0);
+    }
+  }
+  for (int r = 1; r < gpus; r++) { close(sv[r - 1][0]); close(sv[r - 1][1]); }
+  int bad = 0;
+  for (int r = 0; r < gpus; r++) {
+    int st = 0;
+    if (waitpid(pid[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+  }
+  free(sv); free(pid);
+  return bad;
+}
+
 static struct entries *lvq_training(struct teach_params *teach, int kind, float winlen, float epsilon,
                                     float *talpha, const char *who)
 {
@@ -1044,7 +1227,24 @@ struct entries *randinit_codes(struct entries *data, int topol, int neigh, int x
   float *hi = malloc(sizeof(float) * dim), *lo = malloc(sizeof(float) * dim);
   long *cnt = calloc(dim, sizeof(long));
   for (int i = 0; i < dim; i++) { hi[i] = FLT_MIN; lo[i] = FLT_MAX; }
-  for (long r = 0; r < data->num_entries; r++) {
+  if (data->is_virtual) {                              /* the bounding box of a generated source is one pass in HBM */
+    somhip_dataset *ds = mirror_data(data, 0);
+    int64_t *c64 = malloc(sizeof(int64_t) * dim);
+    float *dlo = malloc(sizeof(float) * dim), *dhi = malloc(sizeof(float) * dim);
+    if (!ds || somhip_column_minmax(ds, dlo, dhi, c64)) {
+      fprintf(stderr, "randinit_codes: %s\n", somhip_last_error());
+      free(hi); free(lo); free(cnt); free(c64); free(dlo); free(dhi);
+      if (ds) somhip_dataset_destroy(ds);
+      return NULL;
+    }
+    for (int i = 0; i < dim; i++) {
+      cnt[i] = (long)c64[i];
+      if (cnt[i] > 0) { if (hi[i] < dhi[i]) hi[i] = dhi[i]; if (lo[i] > dlo[i]) lo[i] = dlo[i]; }
+    }
+    somhip_dataset_destroy(ds);
+    free(c64); free(dlo); free(dhi);
+  }
+  for (long r = 0; !data->is_virtual && r < data->num_entries; r++) {
     struct data_entry *e = &data->rows[r];
     for (int i = 0; i < dim; i++)
       if (!(e->mask && e->mask[i])) {

@@ -23,6 +23,7 @@ int main(int argc, char **argv)
   int neighbourhood_weighted = oatoi(extract_parameter(argc, argv, "-qetype", OPTION), 0) > 0;
   teach.radius = oatof(extract_parameter(argc, argv, "-radius", OPTION), 1.0f);
 
+  pak_gen_virtual_ok = 1;                                /* a gen: source is generated in HBM, never on the host */
   if (pak_open_inputs(din, 0, "Can't open data file '%s'\n", cin, 0, "Can't open code file '%s'\n", 2, &io)) exit(1);
   set_teach_params(&teach, io.codes, io.data, funcname);
   set_som_params(&teach);

@@ -9,8 +9,14 @@ static const char *usage =
     "vsom - teach self-organizing map (MI355X engine)\n"
     "Required:  -cin file  -din file  -cout file  -rlen N  -alpha A  -radius R\n"
     "Optional:  -rand seed  -fixed  -weights  -buffer N  -alpha_type linear|inverse_t\n"
-    "           -snapfile name  -snapinterval N  -selfuncs hip  -batch B  -v level\n"
+    "           -snapfile name  -snapinterval N  -selfuncs hip  -batch B  -gpus G  -v level\n"
     "Files:     text (.dat/.cod), raw fp32 (a name ending in .f32; see datconv), or -din gen:k=..,dim=..,n=..,seed=..\n";
+
+static int save_codes(struct teach_params *teach, void *cout)
+{
+  ifverbose(2) fprintf(stderr, "Codebook entries are saved to file %s\n", (char *)cout);
+  return save_entries(teach->codes, (char *)cout) ? 1 : 0;
+}
 
 int main(int argc, char **argv)
 {
@@ -28,7 +34,9 @@ int main(int argc, char **argv)
   use_fixed_level = extract_parameter(argc, argv, "-fixed", OPTION2) != NULL;
   use_weights_level = extract_parameter(argc, argv, "-weights", OPTION2) != NULL;
   long batch = oatoi(extract_parameter(argc, argv, "-batch", OPTION), 1);
+  int gpus = (int)oatoi(extract_parameter(argc, argv, "-gpus", OPTION), 1);   /* new: one process per GPU, codebook sharded */
 
+  pak_gen_virtual_ok = 1;                                /* a gen: source is generated in HBM, never on the host (unless -rand / -buffer) */
   if (pak_open_inputs(cli.din, 0, "cant open data file '%s'\n", cli.cin, 0, "Can't open code file '%s'\n", 1, &io)) goto end;
   set_teach_params(&params, io.codes, io.data, cli.funcname);
   set_som_params(&params);
@@ -39,6 +47,11 @@ int main(int argc, char **argv)
   params.alpha_func = alpha_func_by_name(cli.alpha_s, &params.alpha_type);
   if (!params.alpha_func) { fprintf(stderr, "Unknown alpha type %s\n", cli.alpha_s); goto end; }
 
+  if (gpus > 1 || getenv("SOMHIP_COMM")) {               /* the ranks train; rank 0 saves */
+    if (gpus < 1 || gpus > 64) { fprintf(stderr, "-gpus %d?\n", gpus); goto end; }
+    error = som_training_multi(&params, gpus, save_codes, cli.cout);
+    goto end;
+  }
   if (som_training(&params) == NULL) goto end;           /* (the reference saves regardless) */
   ifverbose(2) fprintf(stderr, "Codebook entries are saved to file %s\n", cli.cout);
   save_entries(io.codes, cli.cout);

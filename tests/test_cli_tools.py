@@ -465,6 +465,37 @@ def test_raw_fp32_reader_rejects_truncated_files(tools, tmp_path):
     assert open(tmp_path / "ok2.f32", "rb").read().endswith(b"a \nb weight=3 \n")
 
 
+@pytest.mark.gpu
+def test_vsom_gpus_flag_equals_one_gpu(tools, tmp_path):
+    """vsom -gpus G (one process per GPU, sharded codebook, all-reduce of winner keys) must write the bytes of the same
+    run on one GPU.  Three ranks sharing this box's GPU exchange their keys over host sockets (RCCL refuses duplicate
+    devices); SOMHIP_COMM=rccl with one rank sends the same loop through ncclAllReduce(ncclUint64, ncclMin) on the
+    engine's stream.  Interleaved 8x8 patches (16x24 map) and contiguous row blocks (12x8 map)."""
+    d = os.path.join(DATA, "ex.dat")
+    for init_args, tag in ((["-xdim", 16, "-ydim", 24], "patch"), (["-xdim", 12, "-ydim", 8], "rows")):
+        init = tmp_path / (tag + "_init.cod")
+        run("randinit", "-din", d, "-cout", init, *init_args, "-topol", "hexa", "-neigh", "bubble", "-rand", 5, "-v", 0)
+        args = ["-din", d, "-cin", init, "-rlen", 3000, "-alpha", 0.05, "-radius", 6, "-batch", 64, "-v", 0]
+        one = tmp_path / (tag + "_one.cod")
+        run("vsom", *args, "-cout", one)
+        three = tmp_path / (tag + "_three.cod")
+        run("vsom", *args, "-cout", three, "-gpus", 3)
+        assert md5(three) == md5(one), tag
+        rccl = tmp_path / (tag + "_rccl.cod")
+        p = subprocess.run([os.path.join(BIN, "vsom")] + [str(a) for a in args] + ["-cout", str(rccl), "-gpus", "1"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, SOMHIP_COMM="rccl"))
+        assert p.returncode == 0, p.stderr
+        assert md5(rccl) == md5(one), tag
+    # a generated source: every rank makes the stream in its own HBM
+    g = "gen:k=8,dim=24,n=4000,seed=77"
+    init = tmp_path / "g_init.cod"
+    run("randinit", "-din", g, "-cout", init, "-xdim", 16, "-ydim", 16, "-topol", "rect", "-neigh", "bubble", "-rand", 2, "-v", 0)
+    a, b = tmp_path / "g1.cod", tmp_path / "g2.cod"
+    run("vsom", "-din", g, "-cin", init, "-cout", a, "-rlen", 4000, "-alpha", 0.04, "-radius", 8, "-batch", 128, "-v", 0)
+    run("vsom", "-din", g, "-cin", init, "-cout", b, "-rlen", 4000, "-alpha", 0.04, "-radius", 8, "-batch", 128, "-gpus", 2, "-v", 0)
+    assert md5(a) == md5(b)
+
+
 # ------------------------------------------------------------------ INTEGRATION.md, proven on the reference's own tools
 REF = os.path.join(ROOT, "oracle", "_ref")
 
