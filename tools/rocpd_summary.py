@@ -47,26 +47,28 @@ def counters(db):
 
 def main():
     src, dst, tag = sys.argv[1:4]
+    commit = sys.argv[4] if len(sys.argv) > 4 else None
     kernel_stats(f"{src}/stats/s_results.db", f"{dst}/{tag}_kernel_stats_bench_default.csv")
     f = counters(f"{src}/pmc_FETCH_SIZE/p_results.db")
     w = counters(f"{src}/pmc_WRITE_SIZE/p_results.db")
     note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), "
-            "bench.py --steps 4 --warmup 1; FETCH_SIZE x2 (gfx950), per-launch averages")
+            "bench.py --steps 8 --warmup 1 --no-full-run: 8 batches of 4096 spread over the 10 M-iteration schedule (radius 128 -> 17); "
+            "FETCH_SIZE x2 (gfx950), per-launch averages")
     res = {}
     for k in sorted(set(f) | set(w)):
         rd = 2.0 * f.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
         wr = w.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
         res[k] = {"read_bytes": rd, "write_bytes": wr, "bytes": rd + wr}
-    json.dump({"source": note, "kernels": res}, open(f"{dst}/{tag}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
+    json.dump({"source": note, "commit": commit, "kernels": res}, open(f"{dst}/{tag}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
     with open(f"{dst}/{tag}_pmc_hbm_traffic.txt", "w") as o:
-        o.write(f"# {note}\n# (first 4 batches of the run: radius ~128).  Calibration: k_rows_to_tiles reads 128 MiB and writes 128 MiB.\n")
+        o.write(f"# {note}\n# Calibration: k_rows_to_tiles reads 128 MiB and writes 128 MiB.\n")
         o.write(f"{'kernel':<28}{'read MiB':>14}{'write MiB':>15}\n")
         for k, v in res.items():
             o.write(f"{k:<28}{v['read_bytes'] / 2**20:>14.1f}{v['write_bytes'] / 2**20:>15.1f}\n")
     sq = counters(f"{src}/pmc_SQ/p_results.db")
     with open(f"{dst}/{tag}_pmc_sq_counters.txt", "w") as o:
         o.write("# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU "
-                "SQ_WAIT_INST_ANY\n#   SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_INSTS_LDS ; bench.py --steps 4 --warmup 1; "
+                "SQ_WAIT_INST_ANY\n#   SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_INSTS_LDS ; bench.py --steps 8 --warmup 1 --no-full-run; "
                 "averages per dispatch\n")
         for k, d in sq.items():
             o.write(k + " " + str({n: f"{v:.4g}" for n, v in sorted(d.items())}) + "\n")
