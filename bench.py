@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--eval-vectors", type=int, default=262144)
     ap.add_argument("--scan", default="auto", choices=["auto", "direct", "mfma", "mfma_bf16"],
                     help="winner-search implementation (all bit-identical); auto = the engine's default")
+    ap.add_argument("--update", default="gemm", choices=["gemm", "exact"],
+                    help="how a mini-batch applies its updates: gemm = affine map of every unit on the fp32 matrix pipe "
+                         "(kernels/som_update_gemm.hpp), exact = adapt_vector's arithmetic hit by hit (bit-identical to the batch oracle)")
     ap.add_argument("--neigh", default="bubble", choices=["bubble", "gaussian"],
                     help="neighbourhood kernel (the headline workload is bubble; gaussian updates every unit for every vector)")
     ap.add_argument("--shards", default="interleaved", choices=["interleaved", "contiguous"],
@@ -159,6 +162,7 @@ def bench_som(a):
     eng = E.Engine(local)
     if a.scan != "auto":
         eng.set_scan_mode(a.scan)
+    eng.set_update_mode(a.update)
     ds = E.Dataset(eng, generate=(seed, kcent, d, 0, L))
     lo, hi, cnt = E.column_minmax(ds)
     init = E.randinit_from_bbox(lo, hi, cnt, xdim, ydim, init_seed)     # = randinit -rand 7 on the same source
@@ -210,7 +214,7 @@ def bench_som(a):
 
     # ---- timed region: exactly K steps, scan -> all-reduce -> update enqueued back to back on the engine's stream ----
     if world > 1:      # N > 1: steps are short; event only the kernels the roofline lines need
-        eng.timing_select({"k_som_update_run", "k_som_update_bubble_s", "k_dist_mfma_bf16", "k_dist_mfma", "k_scan_exact"})
+        eng.timing_select({"k_som_update_run", "k_som_update_bubble_s", "k_som_update_gemm", "k_dist_mfma_bf16", "k_dist_mfma", "k_scan_exact"})
     eng.timing(True)
     eng.timing_reset()
     stats_before = eng.scan_stats()
@@ -319,6 +323,18 @@ def bench_som(a):
                              "frac": alg / avg_s / 1e12 / PEAK_F32_TFLOPS,
                              "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) distance GEMM, 2*N*d flop per vector"})
                 return base
+            if kname == "k_som_update_gemm":
+                walked = (stats_after["gemm_entries"] - stats_before["gemm_entries"]) / max(kl, 1)
+                alg = 3.0 * d * rows_upd / max(kl, 1)           # what the reference's arithmetic spends on these updates
+                exe = 2.0 * d * 64.0 * walked                   # what the matrix pipe executed (64 units per walked entry)
+                base.update({"bound": "mfma", "achieved": exe / avg_s / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                             "frac": exe / avg_s / 1e12 / PEAK_F32_TFLOPS, "algorithmic_tflops": alg / avg_s / 1e12,
+                             "note": "neighbourhood update of a batch as c' = P c + W X on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 "
+                                     "accumulate): achieved = EXECUTED 2*d*64 flop per walked list entry (%.0f per launch; hits whose weight "
+                                     "decayed below 2^-32 are skipped) over the fp32 matrix peak; algorithmic_tflops = the reference's "
+                                     "3*d flop per (row, iteration) update (%.0f per launch) at this kernel's time"
+                                     % (walked, rows_upd / max(kl, 1))})
+                return base
             if kname in ("k_scan_exact", "k_som_update_run", "k_som_update_bubble_s"):
                 if kname == "k_scan_exact":
                     alg = 3.0 * n_local * d * B                 # direct form: sub, mul, add
@@ -376,7 +392,7 @@ def bench_som(a):
                        "timed_steps": "%d steps of %d vectors at iterations k*%d of the %d-iteration schedule (radius %g -> 1 across them)" % (K, B, stride, L, radius),
                        "alpha": a.alpha, "radius": radius, "alpha_type": "linear",
                        "stream": "gen:k=%d,dim=%d,n=%d,seed=%d (somhip_dataset_generate); randinit -rand %d" % (kcent, d, L, seed, init_seed),
-                       "schedule": sched,
+                       "schedule": sched, "update_mode": a.update,
                        "parallelism": "codebook sharded (%s), all-reduce(MIN) of (dist,idx) keys" % layout
                        if world > 1 else "single GPU",
                        "commit": git_head()},

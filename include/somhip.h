@@ -66,11 +66,22 @@ int  somhip_engine_sync(somhip_engine *e);
  * SOMHIP_SCAN_MFMA_BF16). */
 enum { SOMHIP_SCAN_DIRECT = 0, SOMHIP_SCAN_MFMA = 1, SOMHIP_SCAN_MFMA_BF16 = 2 };
 int  somhip_engine_set_scan_mode(somhip_engine *e, int mode);
+/* How a mini-batch (batch > 1) applies its neighbourhood updates:
+ *   SOMHIP_UPDATE_EXACT  adapt_vector's arithmetic, hit after hit (lvq_pak.c:348-349: sub, mul, add, each rounded):
+ *                        bit-identical to orc_som_training(batch) in oracle/ -- the default
+ *   SOMHIP_UPDATE_GEMM   the same affine map of every unit, c' = P c + sum_j w_j x_j, evaluated as a matrix product
+ *                        on the fp32 matrix pipe (kernels/som_update_gemm.hpp); same result up to fp32 rounding of a
+ *                        sum instead of a chain, hits whose weight has decayed below 2^-32 skipped; bubble
+ *                        neighbourhoods, no masked components, dim a multiple of 128 (otherwise the exact kernels run)
+ * batch == 1 (the reference's online algorithm) is not affected.  Environment: SOMHIP_UPDATE_MODE=gemm|exact. */
+enum { SOMHIP_UPDATE_EXACT = 0, SOMHIP_UPDATE_GEMM = 1 };
+int  somhip_engine_set_update_mode(somhip_engine *e, int mode);
 /* cumulative re-rank statistics of the MFMA path since engine creation:
  * out[0] = row groups re-ranked, out[1] = rows re-ranked, out[2] = max groups for one sample,
  * out[3] = samples searched, out[4] = (row, iteration) updates applied by mini-batch runs,
- * out[5] = (row group, iteration) pairs with at least one update */
-int  somhip_scan_stats(somhip_engine *e, uint64_t out[6]);
+ * out[5] = (row group, iteration) pairs with at least one update, out[6] = list entries ((row group, iteration)
+ * pairs) the GEMM-form update walked (it stops where the weights have decayed away), out[7] reserved */
+int  somhip_scan_stats(somhip_engine *e, uint64_t out[8]);
 
 /* diagnostics (tests): run only the pre-filter of the current scan mode on data rows
  * [first, first+count) and return its raw outputs: wmin[ngroups][*bpad] (group minima of

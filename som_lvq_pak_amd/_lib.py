@@ -41,6 +41,7 @@ SIGNATURES = {
     "somhip_engine_stream": (C.c_void_p, [C.c_void_p]),
     "somhip_engine_sync": (C.c_int, [C.c_void_p]),
     "somhip_engine_set_scan_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "somhip_engine_set_update_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "somhip_scan_stats": (C.c_int, [C.c_void_p, c_u64_p]),
     "somhip_lvq_stats": (C.c_int, [C.c_void_p, c_u64_p]),
     "somhip_column_sums": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(C.c_int64)]),

@@ -25,6 +25,7 @@
 #include "kernels/prefilter_mfma.hpp"
 #include "kernels/scan_masked.hpp"
 #include "kernels/som_update.hpp"
+#include "kernels/som_update_gemm.hpp"
 #include "kernels/som_online.hpp"
 #include "kernels/rerank.hpp"
 #include "kernels/lvq.hpp"

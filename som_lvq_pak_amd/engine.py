@@ -58,11 +58,15 @@ class Engine:
         """'direct', 'mfma' or 'mfma_bf16' (see include/somhip.h)"""
         check(self.lib.somhip_engine_set_scan_mode(self.h, {"direct": 0, "mfma": 1, "mfma_bf16": 2}[mode]))
 
+    def set_update_mode(self, mode):
+        """'exact' (adapt_vector's arithmetic, bit-identical to the batch oracle) or 'gemm' (matrix-pipe form)"""
+        check(self.lib.somhip_engine_set_update_mode(self.h, {"exact": 0, "gemm": 1}[mode]))
+
     def scan_stats(self):
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 8)()
         check(self.lib.somhip_scan_stats(self.h, out))
         return {"groups": out[0], "rows": out[1], "max_groups_per_sample": out[2], "samples": out[3],
-                "row_updates": out[4], "group_updates": out[5]}
+                "row_updates": out[4], "group_updates": out[5], "gemm_entries": out[6]}
 
     def lvq_stats(self):
         """exact batched LVQ: codebook rescans (batches) and samples so far"""

@@ -962,3 +962,95 @@ def test_lvq_row_sharded_equals_online():
     p = subprocess.run([sys.executable, "-c", _LVQ_SHARDED_CHILD % (ROOT, ROOT)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=600)
     assert "RESULT True" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
+
+
+# --------------------------------------------------------------------------- update mode "gemm"
+@pytest.mark.parametrize("xd,yd,d,n,B,radius,alpha", [(64, 64, 128, 4096, 2048, 30.0, 0.05), (24, 40, 256, 3000, 1500, 9.0, 0.03),
+                                                       (16, 16, 512, 4096, 4096, 30.0, 0.05), (48, 32, 384, 2048, 1024, 2.0, 0.02)])
+def test_gemm_update_mode_equals_exact_within_rounding(eng, E, oracle, xd, yd, d, n, B, radius, alpha):
+    """SOMHIP_UPDATE_GEMM evaluates the batch's updates of every unit as one affine map c' = P c + sum w_j x_j on the fp32
+    matrix pipe (kernels/som_update_gemm.hpp).  Same winners (they are found before the update), and a codebook that
+    differs from the exact kernels' -- which equal the batch oracle bit for bit -- only by the rounding of a sum instead
+    of a chain: a few fp32 ulps of the data's scale.  The 16x16 case puts all 4096 samples into every unit's list: the
+    walk stops where the weights have decayed below 2^-32 (~440 hits at alpha 0.05) and must still agree."""
+    ds = E.Dataset(eng, generate=(11, 16, d, 0, n))
+    lo, hi, cnt = E.column_minmax(ds)
+    init = E.randinit_from_bbox(lo, hi, cnt, xd, yd, 5)
+    x = ds.rows(0, n)
+    # the 16x16 case runs the first batch of a LONG schedule (rate and radius stay at their initial values inside the
+    # batch, as in a real run); the oracle replays whole schedules only, so there the exact kernels are the yardstick
+    length = 64 * B if (xd, yd) == (16, 16) else B
+    want, wi = None, None
+    if length == B:
+        want, wi, _ = oracle.som_train(init, xd, yd, 3, 1, x, B, alpha, radius, batch=B)
+    got = {}
+    for mode in ("exact", "gemm"):
+        eng.set_update_mode(mode)
+        try:
+            cb = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, xd, yd)
+            s0 = eng.scan_stats()
+            ti, _ = E.som_train(cb, ds, length, alpha, radius, batch=B, count=B)
+            s1 = eng.scan_stats()
+            got[mode] = (cb.download(), ti, s1["gemm_entries"] - s0["gemm_entries"], s1["group_updates"] - s0["group_updates"])
+            cb.close()
+        finally:
+            eng.set_update_mode("exact")
+    if want is None:
+        want, wi = got["exact"][0], got["exact"][1]
+    assert np.array_equal(got["exact"][1], wi) and np.array_equal(got["gemm"][1], wi)
+    assert np.array_equal(bits(got["exact"][0]), bits(want))
+    assert got["exact"][2] == 0 and got["gemm"][2] > 0                       # the matrix-pipe kernel really ran
+    scale = float(np.abs(want).max())
+    assert float(np.abs(got["gemm"][0] - want).max()) <= 8e-6 * scale
+    if (xd, yd) == (16, 16):
+        assert got["gemm"][2] < 0.3 * got["gemm"][3]                          # most of every 4096-entry list skipped
+    ds.close()
+
+
+def test_gemm_update_mode_falls_back_and_shards_identically(eng, E, oracle):
+    """gemm mode is taken only where it applies (bubble, no masks, dim % 128 == 0): a dim-48 map, a gaussian map and
+    masked data must give the exact kernels' bits; interleaved shards in gemm mode give the unsharded gemm bits."""
+    from som_lvq_pak_amd._lib import SomParams
+    eng.set_update_mode("gemm")
+    try:
+        x, _ = synth(7, 900, 48)
+        ini = oracle.randinit(x, 16, 8, 3)
+        for neigh in (1, 2):
+            want, _, _ = oracle.som_train(ini, 16, 8, 3, neigh, x, 600, 0.05, 5.0, batch=100, trace=False)
+            cb, ds = E.Codebook(eng, ini, 3, neigh, 16, 8), E.Dataset(eng, x)
+            E.som_train(cb, ds, 600, 0.05, 5.0, batch=100, trace=False)
+            assert np.array_equal(bits(cb.download()), bits(want)), neigh
+            cb.close(); ds.close()
+        # sharded == unsharded, gemm kernels on both sides
+        d, n, B, xd, yd = 128, 2048, 512, 32, 24
+        ds = E.Dataset(eng, generate=(5, 8, d, 0, n))
+        lo, hi, cnt = E.column_minmax(ds)
+        ini = E.randinit_from_bbox(lo, hi, cnt, xd, yd, 9)
+        cb = E.Codebook(eng, ini, 3, 1, xd, yd)
+        E.som_train(cb, ds, 2 * B, 0.05, 10.0, batch=B, trace=False)
+        whole = cb.download()
+        shards = []
+        for r in range(3):
+            units = E.shard_units(xd, yd, r, 3, eng.lib)
+            shards.append((units, E.Codebook(eng, ini[units], 3, 1, xd, yd, interleave=(r, 3))))
+        kb = eng.device_alloc(8 * B)
+        p = SomParams(2 * B, 0.05, 10.0, 1, 0, 0, B, 0, 2 * B, 0)
+        for it0 in range(0, 2 * B, B):
+            ks = []
+            for _, s in shards:
+                E.check(eng.lib.somhip_batch_winner_keys(s.h, ds.h, it0, B, kb))
+                k = np.empty(B, dtype=np.uint64)
+                E.check(eng.lib.somhip_copy_to_host(eng.h, k.ctypes.data_as(C.c_void_p), kb, 8 * B))
+                ks.append(k)
+            merged = np.minimum(np.minimum(ks[0], ks[1]), ks[2])
+            E.check(eng.lib.somhip_copy_to_device(eng.h, kb, merged.ctypes.data_as(C.c_void_p), 8 * B))
+            for _, s in shards:
+                E.check(eng.lib.somhip_som_batch_update(s.h, ds.h, C.byref(p), it0, B, it0, kb))
+        eng.sync()
+        eng.device_free(kb)
+        full = np.empty_like(whole)
+        for units, s in shards:
+            full[units] = s.download()
+        assert np.array_equal(bits(full), bits(whole))
+    finally:
+        eng.set_update_mode("exact")
