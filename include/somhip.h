@@ -80,7 +80,8 @@ int  somhip_engine_set_update_mode(somhip_engine *e, int mode);
  * out[0] = row groups re-ranked, out[1] = rows re-ranked, out[2] = max groups for one sample,
  * out[3] = samples searched, out[4] = (row, iteration) updates applied by mini-batch runs,
  * out[5] = (row group, iteration) pairs with at least one update, out[6] = list entries ((row group, iteration)
- * pairs) the GEMM-form update walked (it stops where the weights have decayed away), out[7] reserved */
+ * pairs) the GEMM-form update walked (it stops where the weights have decayed away), out[7] = (row group, sample) pairs
+ * that survived level 1 of the two-level pre-filter and went through the three-product level 2 */
 int  somhip_scan_stats(somhip_engine *e, uint64_t out[8]);
 
 /* diagnostics (tests): run only the pre-filter of the current scan mode on data rows

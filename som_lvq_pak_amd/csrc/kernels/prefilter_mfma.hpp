@@ -59,10 +59,14 @@ struct RerankInit {
   int64_t bpad;
   int ncols;
   uint64_t key_init;     // KEY_NONE, or INT64_MAX when the keys go straight into a signed MIN all-reduce
+  uint32_t *l2_gmin1;    // two-level pre-filter: per-sample level-1 minimum (preset to the largest ordered value) ...
+  uint32_t *l2_cnt;      // ... and the survivor count of every row group (preset to 0); null when one level runs
+  int64_t l2_ngroups;
 };
 __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int d, int64_t first,
                              int64_t count, const unsigned int *__restrict__ cn_max_bits,
-                             double err_coeff, float *__restrict__ tau, RerankInit init) {
+                             double err_coeff, float *__restrict__ tau, RerankInit init,
+                             double err_coeff1 = 0.0, float *__restrict__ tau1 = nullptr) {
   const int64_t b = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (init.gmin) {                                       // 64 * count threads >= bpad + 4 * ncols
@@ -71,6 +75,11 @@ __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int
     if (t < init.bpad) { init.gmin[t] = 0xFFFFFFFFu; init.gmin[init.bpad + t] = 0u; }
     if (t < 4 * static_cast<int64_t>(init.ncols)) init.gmin[2 * init.bpad + t] = 0u;
     if (t == 0) *init.pair_count = 0u;
+    if (init.l2_cnt) {
+      if (t < init.bpad) init.l2_gmin1[t] = 0xFFFFFFFFu;
+      const int64_t nthreads = static_cast<int64_t>(gridDim.x) * blockDim.x;
+      for (int64_t k = t; k < init.l2_ngroups; k += nthreads) init.l2_cnt[k] = 0u;
+    }
   }
   if (b >= count) return;
   const float *x = rows + ((first + b) % n_rows) * d;
@@ -87,6 +96,12 @@ __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int
     float tf = static_cast<float>(t);
     if (static_cast<double>(tf) < t) tf = __uint_as_float(__float_as_uint(tf) + 1);   // round up
     tau[b] = tf;
+    if (tau1) {                                          // the level-1 (one-product) window of the two-level pre-filter
+      const double t1 = 2.0 * err_coeff1 * s * s * 1.001;
+      float t1f = static_cast<float>(t1);
+      if (static_cast<double>(t1f) < t1) t1f = __uint_as_float(__float_as_uint(t1f) + 1);
+      tau1[b] = t1f;
+    }
   }
 }
 
@@ -658,6 +673,228 @@ __global__ __launch_bounds__(256, 2) void k_dist_mfma_bf16_wide(CbView cb, int d
   for (int h2 = 0; h2 < 2; h2++) {
     f32x16 sub[2][2] = {{acc[0][2 * h2], acc[0][2 * h2 + 1]}, {acc[1][2 * h2], acc[1][2 * h2 + 1]}};
     prefilter_epilogue(cb, sub, g0 + wr, st0 + wc * 4 + 2 * h2, nst, lane, cn, tau, count, bpad, wmin, wmask);
+  }
+}
+
+// =====================================================================================
+// K2c: TWO-LEVEL pre-filter (round 2).  Level 1 is the same GEMM with ONE bf16 product per K-step, hi x hi: a third of
+// the matrix work and half the operand bytes.  Dropping both lo terms costs |<c,x> - <c_hi,x_hi>| <= 2^-8 (1 + 2^-8)
+// ||c|| ||x||, so s~1 is within delta1 ~ 2^-7 ||c|| ||x|| of s and the group of the exact winner has
+// wmin1 <= min wmin1 + tau1, tau1 = 2 delta1 (host: prefilter_err_coeff_l1).  Over a whole configs[3] run that keeps
+// 2 ... 17 of the 1024 row groups per sample (tools/survivor_study.py).  Level 2 (k_dist_l2) runs the three-product
+// GEMM on exactly those (group, sample) pairs -- gathered by group, the samples' bf16 pieces loaded per lane -- and
+// writes the wmin / wmask the exact re-rank already consumes.  Entries of wmin that level 2 did not touch keep their
+// level-1 value, which exceeds the sample's true minimum by more than delta1 >= 3 delta3: the re-rank's test
+// wmin <= gmin + tau3 never selects them.
+// =====================================================================================
+__device__ __forceinline__ void prefilter_epilogue_min(const CbView &cb, f32x16 (&acc)[2][2], int64_t g, int64_t st_first,
+                                                       int64_t nst, int lane, const float *__restrict__ cn, int64_t bpad,
+                                                       float *__restrict__ wmin) {
+  if (g >= cb.ngroups) return;
+  const int half = lane >> 5, l31 = lane & 31;
+  float4 cnv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      cnv[i][k] = *reinterpret_cast<const float4 *>(cn + g * 64 + 32 * i + 8 * k + 4 * half);
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int64_t st = st_first + j;
+    if (st >= nst) continue;
+    const int64_t b = st * 32 + l31;
+    float m = 3.4e38f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float4 c4 = cnv[i][r >> 2];
+        const float cnr = (r & 3) == 0 ? c4.x : (r & 3) == 1 ? c4.y : (r & 3) == 2 ? c4.z : c4.w;
+        m = fminf(m, cnr - 2.0f * acc[i][j][r]);
+      }
+    m = fminf(m, __shfl_xor(m, 32, WAVE));
+    if (half == 0 && b < bpad) wmin[g * bpad + b] = m;
+  }
+}
+
+// level 1: 128 codes x 256 samples per workgroup as the wide kernel; a stage is BD_KB = 4 k-blocks (two k-steps) of
+// the hi arrays only: wave (arr, sel) brings k-blocks [2 arr, 2 arr + 2) of code group sel and of sample tiles 4 sel ..
+template <int BD_KB>
+__global__ __launch_bounds__(256, 2) void k_dist_mfma_bf16_l1(CbView cb, int d8, const uint4 *__restrict__ chi,
+                                                              const uint4 *__restrict__ xhi, const float *__restrict__ cn,
+                                                              int64_t bpad, float *__restrict__ wmin) {
+  static_assert(BD_KB == 4, "two k-steps per stage, one per staging half");
+  constexpr int CH = 0, XH = 2 * BD_KB * 64, TOT = XH + 8 * BD_KB * 32;
+  __shared__ uint4 lds[2 * TOT];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int64_t g0 = static_cast<int64_t>(blockIdx.y) * 2;
+  const int64_t st0 = static_cast<int64_t>(blockIdx.x) * 8;
+  const int64_t nst = bpad / 32;
+  const int arr = wave & 1, sel = wave >> 1;
+  const int64_t gsrc = g0 + sel < cb.ngroups ? g0 + sel : cb.ngroups - 1;
+  const uint4 *pc = chi + (gsrc * d8 + 2 * arr) * 64 + lane;
+  const uint4 *px[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int64_t ts = st0 + 4 * sel + t < nst ? st0 + 4 * sel + t : nst - 1;
+    px[t] = xhi + (ts * d8 + 2 * arr) * 32 + lane;
+  }
+  const int dc = CH + (sel * BD_KB + 2 * arr) * 64;
+  const int dx = XH + ((4 * sel) * BD_KB + 2 * arr) * 32;             // + t * BD_KB * 32
+  const int nstage = d8 / BD_KB;
+  auto issue = [&](int s) {
+    uint4 *buf = lds + (s & 1) * TOT;
+    const int kb0 = s * BD_KB;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      __builtin_amdgcn_global_load_lds((glb_void *)(pc + (kb0 + k) * 64), (lds_void *)(buf + dc + k * 64), 16, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; t++)      // one instruction moves k-blocks kb0 + 2 arr and + 1 of a tile (lanes 0-31 / 32-63)
+      __builtin_amdgcn_global_load_lds((glb_void *)(px[t] + kb0 * 32), (lds_void *)(buf + dx + t * BD_KB * 32), 16, 0, 0);
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+  issue(0);
+  for (int s = 0; s < nstage; s++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < nstage) issue(s + 1);
+    const uint4 *buf = lds + (s & 1) * TOT;
+#pragma unroll
+    for (int m = 0; m < BD_KB / 2; m++) {
+      const int kb = 2 * m + half;
+      bf16x8 ah[2], bh[4];
+#pragma unroll
+      for (int i = 0; i < 2; i++) ah[i] = __builtin_bit_cast(bf16x8, buf[CH + (wr * BD_KB + kb) * 64 + 32 * i + l31]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) bh[j] = __builtin_bit_cast(bf16x8, buf[XH + ((wc * 4 + j) * BD_KB + kb) * 32 + l31]);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int h2 = 0; h2 < 2; h2++) {
+    f32x16 sub[2][2] = {{acc[0][2 * h2], acc[0][2 * h2 + 1]}, {acc[1][2 * h2], acc[1][2 * h2 + 1]}};
+    prefilter_epilogue_min(cb, sub, g0 + wr, st0 + wc * 4 + 2 * h2, nst, lane, cn, bpad, wmin);
+  }
+}
+
+// survivors of level 1, gathered by row group: list[g][0 .. cnt[g]) = the samples b with wmin1[g][b] <= gmin1[b] + tau1[b].
+// Grid: (32-sample columns, chunks of groups), as the re-rank's select.
+__global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t count, int64_t bpad, int64_t chunk,
+                                                   const float *__restrict__ wmin, const uint32_t *__restrict__ gmin1,
+                                                   const float *__restrict__ tau1, uint32_t *__restrict__ cnt,
+                                                   uint16_t *__restrict__ list) {
+  const int tid = threadIdx.x, bx = tid & 31, gy = tid >> 5, lane = tid & 63;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 32 + bx;
+  const int64_t g_lo = static_cast<int64_t>(blockIdx.y) * chunk;
+  const int64_t g_hi = g_lo + chunk < ngroups ? g_lo + chunk : ngroups;
+  float thr = -3.4e38f;
+  if (b < count) {
+    const uint32_t o = gmin1[b];                         // order-preserving image of the float minimum (float_to_ordered)
+    thr = __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o) + tau1[b];
+  }
+  // a half-wave (32 samples) looks at one group per trip: one reservation per half-wave and group, not one per survivor
+  for (int64_t g0 = g_lo; g0 < g_hi; g0 += 8) {
+    const int64_t g = g0 + gy;
+    const bool in = g < g_hi && b < count && wmin[g * bpad + b] <= thr;
+    const unsigned long long bal = __ballot(in);
+    const uint32_t mine = static_cast<uint32_t>(lane < 32 ? bal : bal >> 32);
+    uint32_t base = 0;
+    if (bx == 0 && mine) base = atomicAdd(&cnt[g], static_cast<uint32_t>(__popc(mine)));
+    base = __shfl(base, lane & 32, WAVE);
+    if (in) list[g * bpad + base + __popc(mine & ((1u << bx) - 1u))] = static_cast<uint16_t>(b);
+  }
+}
+
+// level 2: the three-product GEMM of one row group against tiles of 32 of ITS surviving samples; one wave per tile,
+// operands straight from global memory (each lane loads the 16-byte pieces the MFMA wants from it: for B the piece
+// of its own gathered sample).  Writes wmin / wmask of the (group, sample) pairs it covers.
+__global__ __launch_bounds__(256) void k_dist_l2(CbView cb, int d8, const uint4 *__restrict__ chi, const uint4 *__restrict__ clo,
+                                                 const uint4 *__restrict__ xhi, const uint4 *__restrict__ xlo,
+                                                 const float *__restrict__ cn, const float *__restrict__ tau, int64_t bpad,
+                                                 const uint32_t *__restrict__ cnt, const uint16_t *__restrict__ list,
+                                                 float *__restrict__ wmin, uint64_t *__restrict__ wmask,
+                                                 unsigned long long *__restrict__ stats) {
+  const int64_t g = blockIdx.x;
+  const int n = static_cast<int>(cnt[g]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+  const int ntiles = (n + 31) >> 5;
+  if (stats && threadIdx.x == 0 && blockIdx.y == 0 && n) atomicAdd(stats, static_cast<unsigned long long>(n));
+  // the tiles of a group are dealt to the 4 gridDim.y waves that serve it (a group may hold one tile or a hundred)
+  for (int tile = blockIdx.y * 4 + wave; tile < ntiles; tile += 4 * gridDim.y) {
+    const int slot = tile * 32 + l31;
+    const bool valid = slot < n;
+    const int64_t b = list[g * bpad + (valid ? slot : 0)];
+    const uint4 *pa = chi + (g * d8 + half) * 64 + l31, *pl = clo + (g * d8 + half) * 64 + l31;
+    const uint4 *pxh = xhi + ((b >> 5) * d8 + half) * 32 + (b & 31), *pxl = xlo + ((b >> 5) * d8 + half) * 32 + (b & 31);
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+    // k-step ks uses k-blocks 2 ks + half.  The loop is a chain of global-memory round trips (nothing else hides them:
+    // a group often has a single tile), so the operands of FOUR k-steps are requested together: a quarter of the trips.
+    const int nks = d8 / 2;                              // a multiple of 2 (the host takes this path for d8 % 4 == 0)
+    for (int ks0 = 0; ks0 < nks; ks0 += 4) {
+      uint4 rA0[4], rA1[4], rL0[4], rL1[4], rBH[4], rBL[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int o = 2 * (ks0 + u < nks ? ks0 + u : nks - 1);
+        rA0[u] = pa[o * 64]; rA1[u] = pa[o * 64 + 32]; rL0[u] = pl[o * 64]; rL1[u] = pl[o * 64 + 32];
+        rBH[u] = pxh[o * 32]; rBL[u] = pxl[o * 32];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (ks0 + u < nks) {
+          const bf16x8 a0 = __builtin_bit_cast(bf16x8, rA0[u]), a1 = __builtin_bit_cast(bf16x8, rA1[u]);
+          const bf16x8 l0 = __builtin_bit_cast(bf16x8, rL0[u]), l1 = __builtin_bit_cast(bf16x8, rL1[u]);
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, rBH[u]), bl = __builtin_bit_cast(bf16x8, rBL[u]);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bh, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bl, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bl, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, bh, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, bh, acc[1], 0, 0, 0);
+        }
+      }
+    }
+    // same bit <-> row rule as prefilter_epilogue: register r of block i is row 32 i + (r & 3) + 8 (r >> 2) + 4 half
+    float sv[2][16];
+    float m = 3.4e38f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float v = cn[g * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half] - 2.0f * acc[i][r];
+        sv[i][r] = v;
+        m = fminf(m, v);
+      }
+    m = fminf(m, __shfl_xor(m, 32, WAVE));
+    const float thr = m + tau[b];
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (sv[i][r] <= thr) bits |= 1u << (16 * i + r);
+    const uint32_t other = __shfl_xor(bits, 32, WAVE);
+    if (half == 0 && valid) {
+      wmin[g * bpad + b] = m;
+      wmask[g * bpad + b] = static_cast<uint64_t>(bits) | (static_cast<uint64_t>(other) << 32);
+    }
   }
 }
 

@@ -81,13 +81,14 @@ enum KernelId {
   KID_SOM_UPDATE_BUBBLE_S,
   KID_LVQ_COMPONENTS,
   KID_SOM_UPDATE_GEMM,
+  KID_DIST_L2,
   KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {
     "k_scan_exact", "k_som_update_run", "k_som_online_step", "k_lvq_online_step",
     "k_pack_samples", "k_merge_topk", "k_scan_masked", "k_layout", "k_decode_winners",
     "k_dist_mfma", "k_rerank", "k_norms_tau", "k_som_members",
-    "k_rerank_select", "k_rerank_pairs", "k_dist_mfma_bf16", "k_lvq_batch_apply", "k_som_update_bubble_s", "k_lvq_components", "k_som_update_gemm"};
+    "k_rerank_select", "k_rerank_pairs", "k_dist_mfma_bf16", "k_lvq_batch_apply", "k_som_update_bubble_s", "k_lvq_components", "k_som_update_gemm", "k_dist_l2"};
 extern "C" int somhip_kernel_count(void) { return KID_COUNT; }
 extern "C" const char *somhip_kernel_name(int i) { return (i >= 0 && i < KID_COUNT) ? kKernelNames[i] : ""; }
 
@@ -232,8 +233,8 @@ extern "C" int somhip_engine_create(int device, somhip_engine **out) try {
   auto init = [&]() -> int {
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     if (const char *ts = getenv("SOMHIP_TAU_SCALE")) { double v = atof(ts); if (v >= 1.0) e->tau_scale = v; }
-    HIPCHK(hipMalloc((void **)&e->d_stats, (8 + 128 + 8) * sizeof(unsigned long long)));   // + 64 {rows, pairs} update counters + 8 gemm-walk counters
-    HIPCHK(hipMemset(e->d_stats, 0, (8 + 128 + 8) * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&e->d_stats, (8 + 128 + 8 + 1) * sizeof(unsigned long long)));   // + 64 {rows, pairs} update counters + 8 gemm-walk counters + level-2 pairs
+    HIPCHK(hipMemset(e->d_stats, 0, (8 + 128 + 8 + 1) * sizeof(unsigned long long)));
     if (const char *um = getenv("SOMHIP_UPDATE_MODE")) e->update_mode = strcmp(um, "gemm") == 0 ? SOMHIP_UPDATE_GEMM : SOMHIP_UPDATE_EXACT;
     return 0;
   };
@@ -288,14 +289,14 @@ extern "C" int somhip_engine_set_update_mode(somhip_engine *e, int mode) try {
   return 0;
 } ABI_CATCH(somhip_engine_set_update_mode)
 extern "C" int somhip_scan_stats(somhip_engine *e, uint64_t out[8]) try {
-  unsigned long long h[8 + 128 + 8];
+  unsigned long long h[8 + 128 + 8 + 1];
   HIPCHK(hipMemcpyAsync(h, e->d_stats, sizeof h, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   for (int k = 0; k < 64; k++) { h[3] += h[8 + 2 * k]; h[4] += h[8 + 2 * k + 1]; }
   out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = e->samples_searched; out[4] = h[3]; out[5] = h[4];
   out[6] = 0;
   for (int k = 0; k < 8; k++) out[6] += h[8 + 128 + k];
-  out[7] = 0;
+  out[7] = h[8 + 128 + 8];
   return 0;
 } ABI_CATCH(somhip_scan_stats)
 extern "C" int somhip_lvq_stats(somhip_engine *e, uint64_t out[12]) try {

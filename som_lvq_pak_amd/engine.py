@@ -66,7 +66,7 @@ class Engine:
         out = (C.c_uint64 * 8)()
         check(self.lib.somhip_scan_stats(self.h, out))
         return {"groups": out[0], "rows": out[1], "max_groups_per_sample": out[2], "samples": out[3],
-                "row_updates": out[4], "group_updates": out[5], "gemm_entries": out[6]}
+                "row_updates": out[4], "group_updates": out[5], "gemm_entries": out[6], "l2_pairs": out[7]}
 
     def lvq_stats(self):
         """exact batched LVQ: codebook rescans (batches) and samples so far"""
