@@ -407,7 +407,9 @@ def bench_som(a):
                              / max(stats_after["samples"] - stats_before["samples"], 1),
                              "rows_per_sample": (stats_after["rows"] - stats_before["rows"])
                              / max(stats_after["samples"] - stats_before["samples"], 1),
-                             "max_groups_per_sample": stats_after["max_groups_per_sample"]},
+                             "max_groups_per_sample": stats_after["max_groups_per_sample"],
+                             "level2_groups_per_sample": (stats_after["l2_pairs"] - stats_before["l2_pairs"])
+                             / max(stats_after["samples"] - stats_before["samples"], 1)},
             "update_stats": {"row_updates": rows_upd,
                              "lane_efficiency": rows_upd / max(64 * (stats_after["group_updates"] - stats_before["group_updates"]), 1)},
             "kernels_ms": {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in table.items() if v[0]},

@@ -66,7 +66,7 @@ struct RerankInit {
 __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int d, int64_t first,
                              int64_t count, const unsigned int *__restrict__ cn_max_bits,
                              double err_coeff, float *__restrict__ tau, RerankInit init,
-                             double err_coeff1 = 0.0, float *__restrict__ tau1 = nullptr) {
+                             double l1_prod = 0.0, double l1_sq = 0.0, float *__restrict__ tau1 = nullptr) {
   const int64_t b = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (init.gmin) {                                       // 64 * count threads >= bpad + 4 * ncols
@@ -96,8 +96,11 @@ __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int
     float tf = static_cast<float>(t);
     if (static_cast<double>(tf) < t) tf = __uint_as_float(__float_as_uint(tf) + 1);   // round up
     tau[b] = tf;
-    if (tau1) {                                          // the level-1 (one-product) window of the two-level pre-filter
-      const double t1 = 2.0 * err_coeff1 * s * s * 1.001;
+    if (tau1) {                                          // the level-1 (one-product) window of the two-level pre-filter:
+      // |s~1 - s| <= l1_prod ||x|| ||c|| + l1_sq (||x|| + ||c||)^2 =: delta1 (host: prefilter_err_l1), window = 2 delta1.
+      // The product term carries the dropped lo parts; keeping it a PRODUCT matters while the map is still bunched
+      // around the data's mean (||c|| a third of ||x||): (||x|| + ||c||)^2 / 4 would be 1.4x the product there.
+      const double t1 = 2.0 * (l1_prod * sqrt(acc) * cmax + l1_sq * s * s) * 1.001;
       float t1f = static_cast<float>(t1);
       if (static_cast<double>(t1f) < t1) t1f = __uint_as_float(__float_as_uint(t1f) + 1);
       tau1[b] = t1f;
@@ -755,6 +758,82 @@ __global__ __launch_bounds__(256, 2) void k_dist_mfma_bf16_l1(CbView cb, int d8,
       __builtin_amdgcn_global_load_lds((glb_void *)(pc + (kb0 + k) * 64), (lds_void *)(buf + dc + k * 64), 16, 0, 0);
 #pragma unroll
     for (int t = 0; t < 4; t++)      // one instruction moves k-blocks kb0 + 2 arr and + 1 of a tile (lanes 0-31 / 32-63)
+      __builtin_amdgcn_global_load_lds((glb_void *)(px[t] + kb0 * 32), (lds_void *)(buf + dx + t * BD_KB * 32), 16, 0, 0);
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+  issue(0);
+  for (int s = 0; s < nstage; s++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < nstage) issue(s + 1);
+    const uint4 *buf = lds + (s & 1) * TOT;
+#pragma unroll
+    for (int m = 0; m < BD_KB / 2; m++) {
+      const int kb = 2 * m + half;
+      bf16x8 ah[2], bh[4];
+#pragma unroll
+      for (int i = 0; i < 2; i++) ah[i] = __builtin_bit_cast(bf16x8, buf[CH + (wr * BD_KB + kb) * 64 + 32 * i + l31]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) bh[j] = __builtin_bit_cast(bf16x8, buf[XH + ((wc * 4 + j) * BD_KB + kb) * 32 + l31]);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int h2 = 0; h2 < 2; h2++) {
+    f32x16 sub[2][2] = {{acc[0][2 * h2], acc[0][2 * h2 + 1]}, {acc[1][2 * h2], acc[1][2 * h2 + 1]}};
+    prefilter_epilogue_min(cb, sub, g0 + wr, st0 + wc * 4 + 2 * h2, nst, lane, cn, bpad, wmin);
+  }
+}
+
+// The same level-1 GEMM on a 256 codes x 256 samples workgroup tile (8 waves, each 64 x 128 as before): with one
+// product per K-step the kernel is bound by the L2 -> LDS operand traffic, and the square tile moves a third less of it
+// per MFMA ((256 + 256) / (256 * 256) against (128 + 256) / (128 * 256)).  Wave w brings k-blocks [2 (w & 1), + 2) of
+// code group w >> 1 and of sample tiles 2 (w >> 1), 2 (w >> 1) + 1.
+template <int BD_KB>
+__global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1w(CbView cb, int d8, const uint4 *__restrict__ chi,
+                                                               const uint4 *__restrict__ xhi, const float *__restrict__ cn,
+                                                               int64_t bpad, float *__restrict__ wmin) {
+  static_assert(BD_KB == 4, "two k-steps per stage, one per staging half");
+  constexpr int CH = 0, XH = 4 * BD_KB * 64, TOT = XH + 8 * BD_KB * 32;
+  __shared__ uint4 lds[2 * TOT];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;                // this wave multiplies code group wr x sample tiles 4 wc .. 4 wc + 3
+  const int half = lane >> 5, l31 = lane & 31;
+  const int64_t g0 = static_cast<int64_t>(blockIdx.y) * 4;
+  const int64_t st0 = static_cast<int64_t>(blockIdx.x) * 8;
+  const int64_t nst = bpad / 32;
+  const int arr = wave & 1, sel = wave >> 1;
+  const int64_t gsrc = g0 + sel < cb.ngroups ? g0 + sel : cb.ngroups - 1;
+  const uint4 *pc = chi + (gsrc * d8 + 2 * arr) * 64 + lane;
+  const uint4 *px[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const int64_t ts = st0 + 2 * sel + t < nst ? st0 + 2 * sel + t : nst - 1;
+    px[t] = xhi + (ts * d8 + 2 * arr) * 32 + lane;
+  }
+  const int dc = CH + (sel * BD_KB + 2 * arr) * 64;
+  const int dx = XH + ((2 * sel) * BD_KB + 2 * arr) * 32;             // + t * BD_KB * 32
+  const int nstage = d8 / BD_KB;
+  auto issue = [&](int s) {
+    uint4 *buf = lds + (s & 1) * TOT;
+    const int kb0 = s * BD_KB;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      __builtin_amdgcn_global_load_lds((glb_void *)(pc + (kb0 + k) * 64), (lds_void *)(buf + dc + k * 64), 16, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; t++)
       __builtin_amdgcn_global_load_lds((glb_void *)(px[t] + kb0 * 32), (lds_void *)(buf + dx + t * BD_KB * 32), 16, 0, 0);
   };
   f32x16 acc[2][4];

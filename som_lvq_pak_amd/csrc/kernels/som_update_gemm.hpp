@@ -99,11 +99,10 @@ __global__ __launch_bounds__(256, 2) void k_som_update_gemm(CbView cb, const flo
       ok[u] = m.mask != 0ull;
     }
 #pragma unroll
-    for (int u = 0; u < PER; u++) {
+    for (int u = 0; u < PER; u++) {                      // the entry carries where its sample's row starts, in float4 units (K4b)
       const int q = (tid + 256 * u) % F4;
-      const int64_t r = ok[u] ? (data_first + smp[u]) % n_rows : 0;       // (row 0 is always there; its values are dropped)
-      const float4 v = *reinterpret_cast<const float4 *>(rows + r * cb.d + d0 + 4 * q);
-      xr[u] = ok[u] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v = reinterpret_cast<const float4 *>(rows)[static_cast<size_t>(ok[u] ? smp[u] : 0u) + (d0 >> 2) + q];
+      xr[u] = ok[u] ? v : make_float4(0.f, 0.f, 0.f, 0.f);   // (row 0 is always there; its values are dropped)
     }
   };
   auto store_rows = [&](int buf) {
