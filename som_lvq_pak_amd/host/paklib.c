@@ -1026,8 +1026,7 @@ static int som_training_rank(struct teach_params *teach, int rank, int world, in
   void *dkeys = NULL;
   int64_t *units = NULL, n_local = 0;
   float *mine = NULL;
-  if (somhip_device_count(&ndev) || ndev < 1) { fprintf(stderr, "som_training: %s\n", somhip_last_error()); return 1; }
-  g_device = rank % ndev;
+  if (pak_rank_device(rank) < 0 || somhip_device_count(&ndev)) return 1;
   somhip_engine *en = engine();
   if (!en) return 1;
   const char *force = getenv("SOMHIP_COMM");
@@ -1098,8 +1097,63 @@ done:
   return rc;
 }
 
-/* forks the ranks; rank 0 also runs after(teach, arg) -- the tool's "save the codebook" -- before it exits.
- * Returns 0 when every rank succeeded. */
+/* One process per GPU: forks `world` ranks of the calling process -- which has read its files and has NOT touched a GPU
+ * yet -- and runs rank_main(rank, world, fds, arg) in each; fds: rank 0 gets world-1 socket descriptors (peer r at
+ * [r-1]), every other rank one (to rank 0).  Rank r uses device r % (visible GPUs) (pak_rank_device).  Returns 0 when
+ * every rank returned 0. */
+int pak_run_ranks(int world, int (*rank_main)(int rank, int world, int *fds, void *arg), void *arg)
+{
+  if (g_engine) { fprintf(stderr, "the ranks must be started before this process uses a GPU\n"); return 1; }
+  if (world < 1 || world > 64) { fprintf(stderr, "-gpus %d?\n", world); return 1; }
+  int (*sv)[2] = malloc(sizeof(int[2]) * (world > 1 ? world - 1 : 1));
+  for (int r = 1; r < world; r++)
+    if (socketpair(AF_UNIX, SOCK_STREAM, 0, sv[r - 1])) { perror("socketpair"); free(sv); return 1; }
+  pid_t *pid = malloc(sizeof(pid_t) * world);
+  fflush(NULL);
+  for (int r = 0; r < world; r++) {
+    pid[r] = fork();
+    if (pid[r] < 0) { perror("fork"); free(sv); free(pid); return 1; }
+    if (pid[r] == 0) {
+      int *fds = malloc(sizeof(int) * (world > 1 ? world - 1 : 1));
+      for (int q = 1; q < world; q++) {
+        if (r == 0) { fds[q - 1] = sv[q - 1][0]; close(sv[q - 1][1]); }
+        else if (q == r) { fds[0] = sv[q - 1][1]; close(sv[q - 1][0]); }
+        else { close(sv[q - 1][0]); close(sv[q - 1][1]); }
+      }
+      const int rc = rank_main(r, world, fds, arg);
+      pak_shutdown();
+      fflush(NULL);
+      _exit(rc ? 1 : 0);
+    }
+  }
+  for (int r = 1; r < world; r++) { close(sv[r - 1][0]); close(sv[r - 1][1]); }
+  int bad = 0;
+  for (int r = 0; r < world; r++) {
+    int st = 0;
+    if (waitpid(pid[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+  }
+  free(sv); free(pid);
+  return bad;
+}
+int pak_rank_device(int rank)
+{
+  int ndev = 0;
+  if (somhip_device_count(&ndev) || ndev < 1) { fprintf(stderr, "%s\n", somhip_last_error()); return -1; }
+  g_device = rank % ndev;
+  return g_device;
+}
+int pak_sock_write(int fd, const void *b, size_t n) { return sock_write(fd, b, n); }
+int pak_sock_read(int fd, void *b, size_t n) { return sock_read(fd, b, n); }
+
+struct som_multi { struct teach_params *teach; int (*after)(struct teach_params *, void *); void *arg; };
+static int som_multi_rank(int rank, int world, int *fds, void *p)
+{
+  struct som_multi *m = p;
+  int rc = som_training_rank(m->teach, rank, world, fds);
+  if (rc == 0 && rank == 0 && m->after) rc = m->after(m->teach, m->arg);
+  return rc;
+}
+/* vsom -gpus G: the ranks train the sharded map; rank 0 also runs after(teach, arg) -- the tool's "save the codebook" */
 int som_training_multi(struct teach_params *teach, int gpus, int (*after)(struct teach_params *, void *), void *arg)
 {
   if (set_som_params(teach)) { fprintf(stderr, "som_training: can't set SOM parameters\n"); return 1; }
@@ -1113,37 +1167,8 @@ int som_training_multi(struct teach_params *teach, int gpus, int (*after)(struct
     return 1;
   }
   if (teach->snapshot) fprintf(stderr, "som_training: snapshots are not written with -gpus\n");
-  if (g_engine) { fprintf(stderr, "som_training: the ranks must be started before this process uses a GPU\n"); return 1; }
-  int (*sv)[2] = malloc(sizeof(int[2]) * (gpus > 1 ? gpus - 1 : 1));
-  for (int r = 1; r < gpus; r++)
-    if (socketpair(AF_UNIX, SOCK_STREAM, 0, sv[r - 1])) { perror("socketpair"); free(sv); return 1; }
-  pid_t *pid = malloc(sizeof(pid_t) * gpus);
-  fflush(NULL);
-  for (int r = 0; r < gpus; r++) {
-    pid[r] = fork();
-    if (pid[r] < 0) { perror("fork"); free(sv); free(pid); return 1; }
-    if (pid[r] == 0) {
-      int *fds = malloc(sizeof(int) * (gpus > 1 ? gpus - 1 : 1));
-      for (int q = 1; q < gpus; q++) {
-        if (r == 0) { fds[q - 1] = sv[q - 1][0]; close(sv[q - 1][1]); }
-        else if (q == r) { fds[0] = sv[q - 1][1]; close(sv[q - 1][0]); }
-        else { close(sv[q - 1][0]); close(sv[q - 1][1]); }
-      }
-      int rc = som_training_rank(teach, r, gpus, fds);
-      if (rc == 0 && r == 0 && after) rc = after(teach, arg);
-      pak_shutdown();
-      fflush(NULL);
-      _exit(rc ? 1 : 0);
-    }
-  }
-  for (int r = 1; r < gpus; r++) { close(sv[r - 1][0]); close(sv[r - 1][1]); }
-  int bad = 0;
-  for (int r = 0; r < gpus; r++) {
-    int st = 0;
-    if (waitpid(pid[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
-  }
-  free(sv); free(pid);
-  return bad;
+  struct som_multi m = { teach, after, arg };
+  return pak_run_ranks(gpus, som_multi_rank, &m);
 }
 
 static struct entries *lvq_training(struct teach_params *teach, int kind, float winlen, float epsilon,

@@ -36,11 +36,98 @@ static void ask(char answers[Q_COUNT][100])
 static long as_long(const char *a) { return *a ? atol(a) : 0; }
 static float as_float(const char *a) { return *a ? (float)atof(a) : 0.0f; }
 
-int main(int argc, char **argv)
+/* one trial (vfind.c:247-300): randinit with the trial number as seed, the two training parts, the error on the test file */
+struct vfind_job {
+  struct entries *data, *testdata;
+  int topol, neigh, xdim, ydim, weighted_error;
+  short alpha_type;
+  ALPHA_FUNC *alpha_func;
+  const char *funcname, *out;
+  struct { long length; float alpha, radius; const char *what; } part[2];
+  long trials;
+};
+static struct entries *one_trial(struct vfind_job *j, long seed, float *qerror)
 {
   struct teach_params params;
-  char ans[Q_COUNT][100];
   memset(&params, 0, sizeof params);
+  init_random((int)seed);
+  ifverbose(2) fprintf(stderr, "Initializing codebook\n");
+  struct entries *codes = randinit_codes(j->data, j->topol, j->neigh, j->xdim, j->ydim);
+  if (!codes) return NULL;
+  set_teach_params(&params, codes, NULL, j->funcname);
+  params.alpha_type = j->alpha_type; params.alpha_func = j->alpha_func;
+  set_som_params(&params);
+  params.data = j->data;
+  for (int p = 0; p < 2; p++) {
+    params.length = j->part[p].length; params.alpha = j->part[p].alpha; params.radius = j->part[p].radius;
+    ifverbose(2) fprintf(stderr, "Training map, %s part, rlen: %ld alpha: %f\n", j->part[p].what, params.length, params.alpha);
+    if (!som_training(&params)) { close_entries(codes); return NULL; }
+  }
+  params.data = j->testdata;                           /* radius of the second part stays for -qetype 1 */
+  ifverbose(2) fprintf(stderr, "Calculating quantization error\n");
+  *qerror = j->weighted_error ? find_qerror2(&params) : find_qerror(&params);
+  return codes;
+}
+
+/* vfind -gpus G: the trials are independent, so they run as G replicas, one process per GPU; trial
+ * `seed` goes to rank (trials - seed) % G.  Every rank reports its errors and its best map to rank 0, which prints the
+ * lines in the reference's order (seed counting down), keeps the first smallest error as the sequential loop does
+ * (strict <, vfind.c:296) and saves that map: the output is the sequential run's, byte for byte. */
+static int vfind_rank(int rank, int world, int *fds, void *arg)
+{
+  struct vfind_job *j = arg;
+  if (pak_rank_device(rank) < 0) return 1;
+  const long noc = (long)j->xdim * j->ydim, dim = j->data->dimension, nod = j->testdata->num_entries;
+  float *err = malloc(sizeof(float) * (j->trials + 1));
+  for (long s = 0; s <= j->trials; s++) err[s] = FLT_MAX;
+  struct entries *best = NULL;
+  float best_error = FLT_MAX;
+  for (long seed = j->trials; seed > 0; seed--) {
+    if ((j->trials - seed) % world != rank) continue;
+    float q;
+    struct entries *codes = one_trial(j, seed, &q);
+    if (!codes) return 1;
+    err[seed] = q;
+    if (q < best_error) { best_error = q; struct entries *old = best; best = codes; codes = old; }
+    if (codes) close_entries(codes);
+  }
+  float *rows = malloc(sizeof(float) * noc * dim);
+  if (rank != 0) {
+    if (best) memcpy(rows, best->points, sizeof(float) * noc * dim);
+    return pak_sock_write(fds[0], err, sizeof(float) * (j->trials + 1)) || pak_sock_write(fds[0], rows, sizeof(float) * noc * dim);
+  }
+  /* rank 0: everybody's errors, then the best map of the rank that holds the winning trial */
+  float *all = malloc(sizeof(float) * (j->trials + 1)), *theirs = malloc(sizeof(float) * (j->trials + 1));
+  float **maps = calloc(world, sizeof(float *));
+  memcpy(all, err, sizeof(float) * (j->trials + 1));
+  for (int r = 1; r < world; r++) {
+    maps[r] = malloc(sizeof(float) * noc * dim);
+    if (pak_sock_read(fds[r - 1], theirs, sizeof(float) * (j->trials + 1)) || pak_sock_read(fds[r - 1], maps[r], sizeof(float) * noc * dim)) return 1;
+    for (long s = 1; s <= j->trials; s++) if ((j->trials - s) % world == r) all[s] = theirs[s];
+  }
+  float win_error = FLT_MAX;
+  long win_seed = 0;
+  for (long seed = j->trials; seed > 0; seed--) {
+    if (all[seed] < win_error) { win_error = all[seed]; win_seed = seed; }
+    ifverbose(1) fprintf(stderr, "%3ld: %f\n", seed, all[seed] / (float)nod);
+  }
+  if (win_seed > 0) {
+    const int owner = (int)((j->trials - win_seed) % world);
+    /* a rank's best map is the one of its first smallest error: the winning trial is that rank's best */
+    if (owner != 0) {
+      if (!best) { init_random(1); best = randinit_codes(j->data, j->topol, j->neigh, j->xdim, j->ydim); }
+      memcpy(best->points, maps[owner], sizeof(float) * noc * dim);
+    }
+    ifverbose(2) fprintf(stdout, "Codebook entries are saved to file %s\n", j->out);
+    save_entries(best, j->out);
+    ifverbose(1) fprintf(stdout, "Smallest error with random seed %3ld: %f\n", win_seed, win_error / (float)nod);
+  }
+  return 0;
+}
+
+int main(int argc, char **argv)
+{
+  char ans[Q_COUNT][100];
   global_options(argc, argv);
   printf("vfind (MI355X engine): trains a number of randomly initialised maps in two parts each\n"
          "(ordering, fine tuning) and saves the one with the smallest quantization error on the\n"
@@ -62,6 +149,7 @@ int main(int argc, char **argv)
   char *alpha_s = extract_parameter(argc, argv, "-alpha_type", OPTION);
   int weighted_error = oatoi(extract_parameter(argc, argv, "-qetype", OPTION), 0) > 0;
   char *funcname = extract_parameter(argc, argv, "-selfuncs", OPTION);
+  int gpus = (int)oatoi(extract_parameter(argc, argv, "-gpus", OPTION), 1);      /* new: trials as replicas over G GPUs */
 
   int error = 1;
   struct entries *data = NULL, *testdata = NULL, *best = NULL;
@@ -74,24 +162,19 @@ int main(int argc, char **argv)
   ALPHA_FUNC *alpha_func = alpha_func_by_name(alpha_s ? alpha_s : "linear", &alpha_type);
   if (!alpha_func) { fprintf(stderr, "Unknown alpha type %s\n", alpha_s); goto end; }
 
+  struct vfind_job job = { data, testdata, topol, neigh, xdim, ydim, weighted_error, alpha_type, alpha_func, funcname, ans[Q_OUT],
+                           { {part[0].length, part[0].alpha, part[0].radius, part[0].what},
+                             {part[1].length, part[1].alpha, part[1].radius, part[1].what} }, trials };
+  if (gpus > 1) {                                       /* the trials as replicas, one process per GPU */
+    error = pak_run_ranks(gpus, vfind_rank, &job);
+    goto end;
+  }
   float best_error = FLT_MAX;
   long best_seed = 0, nod = testdata->num_entries;
   for (long seed = trials; seed > 0; seed--) {         /* vfind.c:244-306: the seed is the trial counter */
-    init_random((int)seed);
-    ifverbose(2) fprintf(stderr, "Initializing codebook\n");
-    struct entries *codes = randinit_codes(data, topol, neigh, xdim, ydim);
-    set_teach_params(&params, codes, NULL, funcname);
-    params.alpha_type = alpha_type; params.alpha_func = alpha_func;
-    set_som_params(&params);
-    params.data = data;
-    for (int p = 0; p < 2; p++) {
-      params.length = part[p].length; params.alpha = part[p].alpha; params.radius = part[p].radius;
-      ifverbose(2) fprintf(stderr, "Training map, %s part, rlen: %ld alpha: %f\n", part[p].what, params.length, params.alpha);
-      if (!som_training(&params)) goto end;
-    }
-    params.data = testdata;                            /* radius of the second part stays for -qetype 1 */
-    ifverbose(2) fprintf(stderr, "Calculating quantization error\n");
-    float qerror = weighted_error ? find_qerror2(&params) : find_qerror(&params);
+    float qerror;
+    struct entries *codes = one_trial(&job, seed, &qerror);
+    if (!codes) goto end;
     if (qerror < best_error) {
       best_error = qerror; best_seed = seed;
       struct entries *old = best; best = codes; codes = old;

@@ -122,6 +122,24 @@ def test_vfind_matches_reference_cli(tools, tmp_path):
 
 
 @pytest.mark.gpu
+def test_vfind_gpus_replicas_equal_the_sequential_run(tools, tmp_path):
+    """vfind -gpus G runs the trials as independent replicas, one process per GPU (two ranks sharing this box's GPU
+    here); rank 0 prints the trials in the reference's order and keeps the first smallest error: same lines, same map
+    as the reference's sequential loop (vfind.c:244-306)."""
+    answers = ["3", "{data}", "{data}", "{out}", "hexa", "bubble", "6", "5", "800", "0.05", "5", "2000", "0.02", "2"]
+    ex = EXPECTED["som"]["vfind"]["q0"]
+    out = tmp_path / "g2.cod"
+    ans = "\n".join(a.format(data=os.path.join(DATA, "ex.dat"), out=out) for a in answers) + "\n"
+    p = subprocess.run([os.path.join(BIN, "vfind"), "-gpus", "2"] + ex["args"], input=ans, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr
+    trials = [ln for ln in p.stderr.splitlines() if ": " in ln and ln.strip()[:1].isdigit()]
+    assert trials == ex["trials_stderr"]
+    assert p.stdout.strip().splitlines()[-1] == ex["last_stdout_line"]
+    assert md5(out) == ex["md5"]
+
+
+@pytest.mark.gpu
 def test_qerror_qetype1_matches_reference_cli(tools):
     """qerror -qetype 1 -radius 2 on the reference's own map (find_qerror2, som_rout.c:823)"""
     p = run("qerror", "-din", os.path.join(DATA, "ex.dat"), "-cin", os.path.join(CLI, "som_hexa_bubble.cod"),
