@@ -12,12 +12,23 @@ static const char *usage =
     "Required:  -cin file  -din file  -cout file  -rlen N\n"
     "           -alpha A (optional for olvq1)   lvq2: -win W   lvq3: -win W -epsilon E\n"
     "Optional:  -type lvq1|olvq1|lvq2|lvq3  -rand seed  -buffer N  -alpha_type linear|inverse_t\n"
-    "           -snapfile name  -snapinterval N  -selfuncs hip  -v level\n";
+    "           -snapfile name  -snapinterval N  -selfuncs hip  -gpus G  -v level\n";
 
 /* which flags each algorithm insists on (lvqtrain.c:144-162) */
 static const struct { const char *name; int kind, alpha_required, win, eps; } kinds[] = {
     {"lvq1", SOMHIP_LVQ1, 1, 0, 0}, {"olvq1", SOMHIP_OLVQ1, 0, 0, 0},
     {"lvq2", SOMHIP_LVQ2, 1, 1, 0}, {"lvq3", SOMHIP_LVQ3, 1, 1, 1}};
+
+struct save_job { const char *cout; float *talpha; long noc; int olvq; };
+static int save_trained(struct teach_params *teach, void *arg)          /* what follows a successful training (lvqtrain.c:245-249) */
+{
+  struct save_job *j = arg;
+  if (j->olvq) alpha_write(j->talpha, j->noc, j->cout);                 /* lvq_rout.c:694 */
+  ifverbose(2) fprintf(stdout, "Codebook entries are saved to file %s\n", j->cout);
+  save_entries(teach->codes, j->cout);
+  invalidate_alphafile(j->cout);                                        /* lvqtrain.c:249 */
+  return 0;
+}
 
 int main(int argc, char **argv)
 {
@@ -53,6 +64,25 @@ int main(int argc, char **argv)
     close_entries(io.data); close_entries(io.codes); exit(1);
   }
 
+  int gpus = (int)oatoi(extract_parameter(argc, argv, "-gpus", OPTION), 1);     /* new: codebook rows sharded over G GPUs */
+  if (gpus > 1 || getenv("SOMHIP_COMM")) {
+    long noc = io.codes->num_entries;
+    float *talpha = malloc(sizeof(float) * (noc + 1)), clamp = alpha;
+    if (kinds[k].kind == SOMHIP_OLVQ1) {                          /* lvq_rout.c:614-627 */
+      if (alpha == 0.0f) {
+        if (!alpha_read(talpha, noc, cli.cin)) { clamp = 0.3f; for (long i = 0; i < noc; i++) talpha[i] = clamp; }
+      } else {
+        for (long i = 0; i < noc; i++) talpha[i] = alpha;
+      }
+    }
+    struct save_job job = { cli.cout, talpha, noc, kinds[k].kind == SOMHIP_OLVQ1 };
+    int bad = lvq_training_multi(&params, kinds[k].kind, winlen, epsilon, clamp, talpha, gpus, save_trained, &job);
+    if (bad) fprintf(stderr, "Teaching failed\n");
+    free(talpha);
+    close_entries(io.data); close_entries(io.codes);
+    pak_shutdown();
+    return bad;
+  }
   struct entries *trained = NULL;
   switch (kinds[k].kind) {
   case SOMHIP_LVQ1: trained = lvq1_training(&params); break;

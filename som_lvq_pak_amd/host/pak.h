@@ -188,6 +188,9 @@ void pak_shutdown(void);
 /* vsom -gpus G: one process per GPU, codebook sharded, RCCL all-reduce of the winner keys (paklib.c).  Must be called
  * before this process has used a GPU; rank 0 runs after(teach, arg) (save the codebook) when training succeeded. */
 int som_training_multi(struct teach_params *teach, int gpus, int (*after)(struct teach_params *, void *), void *arg);
+/* lvqtrain -gpus G: rows of the codebook sharded over the ranks, exact (paklib.c) */
+int lvq_training_multi(struct teach_params *teach, int kind, float winlen, float epsilon, float clamp, float *talpha, int gpus,
+                       int (*after)(struct teach_params *, void *), void *arg);
 /* the launcher behind it, for tools that spread independent work over the GPUs (vfind -gpus G: trials as replicas) */
 int pak_run_ranks(int world, int (*rank_main)(int rank, int world, int *fds, void *arg), void *arg);
 int pak_rank_device(int rank);          /* selects GPU rank % (visible GPUs) for this process's engine; -1 on failure */

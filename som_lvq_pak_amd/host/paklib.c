@@ -1228,6 +1228,124 @@ struct entries *olvq1_training(struct teach_params *teach, const char *infile, c
   return r;
 }
 
+/* ------------------------------------------------------------------ lvq*_training on G GPUs (lvqtrain -gpus G)
+ * The codebook is cut into contiguous row blocks, one per rank; every rank holds the data.  Per batch of <= 1024
+ * iterations (include/somhip.h, "lvq*_training over a ROW-SHARDED codebook"): each rank's 8 nearest rows per sample ->
+ * all-gather + merge -> labels / rates / rows of the listed candidates the rank owns -> all-reduce(SUM) as integers ->
+ * every rank walks the batch (same decisions everywhere) and commits the rows it owns.  Exactly the online result.
+ * Collectives: RCCL when every rank has its own GPU, the parent's socketpairs otherwise (somhip_comm). */
+struct lvq_multi {
+  struct teach_params *teach; int kind; float winlen, epsilon, clamp; float *talpha;
+  int (*after)(struct teach_params *, void *); void *arg;
+};
+
+static int lvq_training_rank(int rank, int world, int *fds, void *pp)
+{
+  struct lvq_multi *m = pp;
+  struct teach_params *teach = m->teach;
+  struct entries *codes = teach->codes, *data = teach->data;
+  const long n = codes->num_entries, dim = codes->dimension, L = teach->length;
+  const long per = (n + world - 1) / world, r0 = rank * per < n ? rank * per : n, r1 = r0 + per < n ? r0 + per : n, nl = r1 - r0;
+  const int knn = m->kind >= SOMHIP_LVQ2 ? 2 : 1, XR = 4, BMAX = 1024;
+  const long d4 = (dim + 3) / 4;
+  int ndev = 0, rc = 1;
+  somhip_comm *comm = NULL;
+  somhip_codebook *cb = NULL;
+  somhip_dataset *ds = NULL;
+  void *dloc = NULL, *dall = NULL, *dkeys = NULL, *dlab = NULL, *dta = NULL, *drows = NULL;
+  float *mine = NULL;
+  if (nl <= 0) { fprintf(stderr, "lvq training: more ranks (%d) than code vectors\n", world); return 1; }
+  if (pak_rank_device(rank) < 0 || somhip_device_count(&ndev)) return 1;
+  somhip_engine *en = engine();
+  if (!en) return 1;
+  const char *force = getenv("SOMHIP_COMM");
+  const int use_rccl = force ? strcmp(force, "rccl") == 0 : ndev >= world;
+  if (use_rccl) {
+    char id[128];
+    if (rank == 0) {
+      if (somhip_comm_unique_id(id)) goto hip_fail;
+      for (int r = 1; r < world; r++) if (sock_write(fds[r - 1], id, sizeof id)) goto done;
+    } else if (sock_read(fds[0], id, sizeof id)) goto done;
+    if (somhip_comm_create(en, id, rank, world, &comm)) goto hip_fail;
+  } else if (somhip_comm_create_sockets(en, rank, world, fds, &comm)) goto hip_fail;
+
+  int32_t *lab = first_labels(codes);
+  if (somhip_codebook_create(en, codes->points + r0 * dim, lab + r0, nl, (int)dim, TOPOL_LVQ, 0, 0, 0, r0, n, &cb)) { free(lab); goto hip_fail; }
+  free(lab);
+  if (m->kind == SOMHIP_OLVQ1 && somhip_lvq_rates_upload(cb, m->talpha + r0)) goto hip_fail;
+  if (!(ds = mirror_data(data, 1))) goto done;
+  if (somhip_device_alloc(en, 8 * 8 * BMAX, &dloc) || somhip_device_alloc(en, (int64_t)8 * 8 * BMAX * world, &dall) ||
+      somhip_device_alloc(en, 8 * 8 * BMAX, &dkeys) || somhip_device_alloc(en, 4 * 8 * BMAX, &dlab) ||
+      somhip_device_alloc(en, 4 * 8 * BMAX, &dta) || somhip_device_alloc(en, (int64_t)BMAX * XR * d4 * 16, &drows)) goto hip_fail;
+
+  somhip_lvq_params lp = { m->kind, L, m->clamp, teach->alpha_type, m->winlen, m->epsilon, 0, 0, 0 };
+  long B = 256;
+  for (long it0 = 0; it0 < L;) {
+    const long c = B < L - it0 ? B : L - it0, first = it0 % data->num_entries;
+    int64_t done = 0;
+    if (somhip_batch_topk_keys(cb, ds, first, c, 8, knn == 2 ? SOMHIP_TIE_KNN : SOMHIP_TIE_FIRST, dloc) ||
+        somhip_comm_allgather(comm, dloc, dall, 8 * 8 * c) ||
+        somhip_merge_topk_keys(en, dall, world, c, 8, dkeys) ||
+        somhip_lvq_batch_candidates(cb, c, m->kind, dkeys, XR, dlab, m->kind == SOMHIP_OLVQ1 ? dta : NULL, drows) ||
+        somhip_comm_allreduce_sum_u32(comm, dlab, 8 * c) ||
+        (m->kind == SOMHIP_OLVQ1 && somhip_comm_allreduce_sum_u32(comm, dta, 8 * c)) ||
+        somhip_comm_allreduce_sum_u32(comm, drows, c * XR * d4 * 4) ||
+        somhip_lvq_batch_apply(cb, ds, &lp, it0, c, first, dkeys, dlab, m->kind == SOMHIP_OLVQ1 ? dta : NULL, drows, XR, &done, NULL, NULL))
+      goto hip_fail;
+    if (done <= 0 || done > c) { fprintf(stderr, "lvq training: batch made no progress\n"); goto done; }
+    it0 += done;
+    B = done == c ? (2 * B < BMAX ? 2 * B : BMAX) : (done + done / 4 + 8 > 32 ? (done + done / 4 + 8 < BMAX ? done + done / 4 + 8 : BMAX) : 32);
+  }
+  /* X3: every rank's rows (and OLVQ1 rates) to rank 0 */
+  mine = malloc(sizeof(float) * nl * (dim + 1));
+  if (somhip_codebook_download(cb, mine)) goto hip_fail;
+  if (m->kind == SOMHIP_OLVQ1 && somhip_lvq_rates_download(cb, mine + nl * dim)) goto hip_fail;
+  if (rank == 0) {
+    memcpy(codes->points, mine, sizeof(float) * nl * dim);
+    if (m->kind == SOMHIP_OLVQ1) memcpy(m->talpha, mine + nl * dim, sizeof(float) * nl);
+    for (int r = 1; r < world; r++) {
+      const long q0 = r * per < n ? r * per : n, q1 = q0 + per < n ? q0 + per : n, nq = q1 - q0;
+      float *buf = malloc(sizeof(float) * (nq + 1) * (dim + 1));
+      const int bad = sock_read(fds[r - 1], buf, sizeof(float) * nq * (dim + 1));
+      if (!bad) {
+        memcpy(codes->points + q0 * dim, buf, sizeof(float) * nq * dim);
+        if (m->kind == SOMHIP_OLVQ1) memcpy(m->talpha + q0, buf + nq * dim, sizeof(float) * nq);
+      }
+      free(buf);
+      if (bad) goto done;
+    }
+    rc = m->after ? m->after(teach, m->arg) : 0;
+  } else {
+    rc = sock_write(fds[0], mine, sizeof(float) * nl * (dim + 1));
+  }
+  goto done;
+hip_fail:
+  fprintf(stderr, "lvq training (rank %d): %s\n", rank, somhip_last_error());
+done:
+  { void *bufs[6] = { dloc, dall, dkeys, dlab, dta, drows }; for (int k = 0; k < 6; k++) if (bufs[k]) somhip_device_free(en, bufs[k]); }
+  if (ds) somhip_dataset_destroy(ds);
+  if (cb) somhip_codebook_destroy(cb);
+  if (comm) somhip_comm_destroy(comm);
+  free(mine);
+  return rc;
+}
+
+/* lvqtrain -gpus G.  talpha: OLVQ1's rates, [noc], filled in by the caller as lvq_rout.c:614-627 does and updated in
+ * rank 0's copy before after(teach, arg) runs there (save the codebook, write the .lra file). */
+int lvq_training_multi(struct teach_params *teach, int kind, float winlen, float epsilon, float clamp, float *talpha, int gpus,
+                       int (*after)(struct teach_params *, void *), void *arg)
+{
+  if (!teach->data || teach->data->num_entries <= 0) { fprintf(stderr, "lvq training: can't get data\n"); return 1; }
+  if (teach->data->random_order && teach->data->buffer > 0 && teach->data->buffer < teach->data->num_entries) {
+    fprintf(stderr, "lvq training: -buffer with -rand is not available with -gpus\n");
+    return 1;
+  }
+  if (teach->data->masks) { fprintf(stderr, "lvq training: masked samples are not supported by the LVQ loops of the engine\n"); return 1; }
+  if (teach->snapshot) fprintf(stderr, "lvq training: snapshots are not written with -gpus\n");
+  struct lvq_multi m = { teach, kind, winlen, epsilon, clamp, talpha, after, arg };
+  return pak_run_ranks(gpus, lvq_training_rank, &m);
+}
+
 int find_all_winners(struct teach_params *teach, int32_t *index, float *diff, int32_t *ret)
 {
   somhip_codebook *cb = mirror_codes(teach->codes, 0);

@@ -514,6 +514,23 @@ def test_vsom_gpus_flag_equals_one_gpu(tools, tmp_path):
     assert md5(a) == md5(b)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["lvq1", "lvq2", "lvq3", "olvq1", "olvq1_default"])
+def test_lvqtrain_gpus_flag_gives_the_reference_bytes(tools, tmp_path, tag):
+    """lvqtrain -gpus 3: the codebook's rows cut into three blocks, one process each (sharing this box's GPU: candidate
+    lists and rows travel over host sockets; SOMHIP_COMM=rccl with one rank goes through ncclAllGather / ncclAllReduce).
+    The LVQ loops over a sharded codebook are exact: the reference's own bytes."""
+    ex = EXPECTED["lvq"][tag]
+    for extra, env in ((["-gpus", 3], {}), (["-gpus", 1], {"SOMHIP_COMM": "rccl"})):
+        out = tmp_path / ("out%s.cod" % extra[1])
+        p = subprocess.run([os.path.join(BIN, ex["tool"]), "-din", os.path.join(DATA, "ex1.dat"), "-cin", os.path.join(CLI, "lvq_init.cod"),
+                            "-cout", str(out)] + [str(a) for a in ex["args"]] + [str(a) for a in extra] + ["-v", "0"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr
+        assert md5(out) == ex["md5"], extra
+        assert not os.path.exists(str(out)[:-4] + ".lra")
+
+
 # ------------------------------------------------------------------ INTEGRATION.md, proven on the reference's own tools
 REF = os.path.join(ROOT, "oracle", "_ref")
 
