@@ -331,7 +331,7 @@ def bench_som(a):
                              "frac": exe / avg_s / 1e12 / PEAK_F32_TFLOPS, "algorithmic_tflops": alg / avg_s / 1e12,
                              "note": "neighbourhood update of a batch as c' = P c + W X on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 "
                                      "accumulate): achieved = EXECUTED 2*d*64 flop per walked list entry (%.0f per launch; hits whose weight "
-                                     "decayed below 2^-32 are skipped) over the fp32 matrix peak; algorithmic_tflops = the reference's "
+                                     "decayed below 2^-24 are skipped) over the fp32 matrix peak; algorithmic_tflops = the reference's "
                                      "3*d flop per (row, iteration) update (%.0f per launch) at this kernel's time"
                                      % (walked, rows_upd / max(kl, 1))})
                 return base

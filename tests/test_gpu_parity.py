@@ -972,7 +972,7 @@ def test_gemm_update_mode_equals_exact_within_rounding(eng, E, oracle, xd, yd, d
     matrix pipe (kernels/som_update_gemm.hpp).  Same winners (they are found before the update), and a codebook that
     differs from the exact kernels' -- which equal the batch oracle bit for bit -- only by the rounding of a sum instead
     of a chain: a few fp32 ulps of the data's scale.  The 16x16 case puts all 4096 samples into every unit's list: the
-    walk stops where the weights have decayed below 2^-32 (~440 hits at alpha 0.05) and must still agree."""
+    walk stops where the weights have decayed below 2^-24 (~330 hits at alpha 0.05) and must still agree."""
     ds = E.Dataset(eng, generate=(11, 16, d, 0, n))
     lo, hi, cnt = E.column_minmax(ds)
     init = E.randinit_from_bbox(lo, hi, cnt, xd, yd, 5)

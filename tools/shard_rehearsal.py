@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--ydim", type=int, default=256)
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--layout", default="interleaved", choices=["interleaved", "contiguous"])
+    ap.add_argument("--update", default="gemm", choices=["gemm", "exact"], help="update mode (bench.py's default: gemm)")
     a = ap.parse_args()
     import torch
     from som_lvq_pak_amd import engine as E
@@ -58,6 +59,7 @@ def main():
     torch.cuda.synchronize()
 
     eng = E.Engine(0)
+    eng.set_update_mode(a.update)
     ds = E.Dataset(eng, device_ptr=data.data_ptr(), n=length, dim=d)
     ext = torch.cuda.ExternalStream(eng.stream, device=dev)
     ref_q = None
