@@ -56,6 +56,16 @@ struct LvqBatchOut {                 // device -> host summary of one walk
   int64_t cycles[4];                 // s_memtime ticks spent in phases A..D, summed over components
 };
 
+// Control block of the batch loop that does not wait for the host (host_lvq.inc: lvq_train_batched).  The host
+// launches batch after batch assuming that each walks to its end; a batch in which a component stopped early does
+// not commit, raises `poison`, and from then on no later batch changes the codebook, the rates or the bf16 copies --
+// until the host has seen the flag, redone that batch the careful way and cleared it.
+struct LvqCtl {
+  int32_t poison;                    // != 0: batch `batch` stopped at sample `limit` for `reason`; nothing later was applied
+  int32_t batch, limit, reason;
+  unsigned long long batches, comps, largest, cycles[4];   // statistics of the batches that were committed
+};
+
 __device__ __forceinline__ float lvq_sq(float c, float x) { const float t = c - x; return t * t; }
 
 // ---- rho_j of relation (*): one wave per sample -------------------------------------------------
@@ -600,9 +610,44 @@ __global__ __launch_bounds__(LVQ_BT) void k_lvq_batch_apply(CbView cb, const flo
 __global__ __launch_bounds__(256) void k_lvq_commit(CbView cb, const LvqBatchOut *__restrict__ out,
                                                     const float4 *__restrict__ stage_rows, const int32_t *__restrict__ stage_rowid,
                                                     const float *__restrict__ stage_ta, float *__restrict__ talpha,
-                                                    int32_t *__restrict__ mod_rows, int32_t *__restrict__ mod_count) {
+                                                    int32_t *__restrict__ mod_rows, int32_t *__restrict__ mod_count,
+                                                    LvqCtl *__restrict__ ctl = nullptr, int batch_id = 0, int batch_len = 0) {
   const int comp = blockIdx.x;
   if (comp >= out->ncomp) return;
+  if (ctl) {                                             // the loop that does not wait for the host: commit only a batch that ran through
+    __shared__ int s_first[256], s_why[256], s_big[256];
+    if (*reinterpret_cast<volatile int32_t *>(&ctl->poison)) return;
+    int mine = 0x7FFFFFFF, why = 0, big = 0;
+    for (int k = threadIdx.x; k < out->ncomp; k += 256) {
+      if (out->stop[k] < mine) { mine = out->stop[k]; why = out->reason[k]; }
+      big = max(big, out->start[k + 1] - out->start[k]);
+    }
+    s_first[threadIdx.x] = mine; s_why[threadIdx.x] = why; s_big[threadIdx.x] = big;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if (threadIdx.x < off) {
+        if (s_first[threadIdx.x + off] < s_first[threadIdx.x]) {
+          s_first[threadIdx.x] = s_first[threadIdx.x + off]; s_why[threadIdx.x] = s_why[threadIdx.x + off];
+        }
+        s_big[threadIdx.x] = max(s_big[threadIdx.x], s_big[threadIdx.x + off]);
+      }
+      __syncthreads();
+    }
+    const int first = s_first[0];
+    if (first < batch_len) {                             // every workgroup of this launch comes to the same verdict
+      if (comp == 0 && threadIdx.x == 0) {
+        ctl->batch = batch_id; ctl->limit = first; ctl->reason = s_why[0];
+        __threadfence();
+        *reinterpret_cast<volatile int32_t *>(&ctl->poison) = 1;
+      }
+      return;
+    }
+    if (comp == 0 && threadIdx.x == 0) {
+      ctl->batches += 1ull; ctl->comps += static_cast<unsigned long long>(out->ncomp);
+      ctl->largest += static_cast<unsigned long long>(s_big[0]);
+      for (int k = 0; k < 4; k++) ctl->cycles[k] += static_cast<unsigned long long>(out->cycles[k]);
+    }
+  }
   const int ns = out->nslots[comp];
   const int64_t stage0 = 2 * static_cast<int64_t>(out->start[comp]);
   for (int sl = 0; sl < ns; sl++) {

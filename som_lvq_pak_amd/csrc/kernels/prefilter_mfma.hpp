@@ -326,8 +326,10 @@ __global__ void k_prep_codes_bf16(CbView cb, int d8, float *__restrict__ cn,
 __global__ __launch_bounds__(256) void k_prep_rows_bf16(CbView cb, int d8, const int32_t *__restrict__ list,
                                                         int nlist, const int32_t *__restrict__ nlist_dev,
                                                         float *__restrict__ cn,
-                                                        uint4 *__restrict__ chi, uint4 *__restrict__ clo) {
+                                                        uint4 *__restrict__ chi, uint4 *__restrict__ clo,
+                                                        const int32_t *__restrict__ skip = nullptr) {
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (skip && *skip) return;                                    // (the LVQ loop's poison flag: the batch was not committed)
   if (w >= nlist || (nlist_dev && w >= *nlist_dev)) return;     // nlist: launch bound; *nlist_dev: the list's length on the device
   const int64_t row = list[w];
   const int64_t g = row >> 6;

@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void k_rerank_topk(CbView cb, const float *__r
                                                      int64_t n_rows, int64_t first, int64_t count,
                                                      int64_t bpad, const float *__restrict__ wmin,
                                                      const float *__restrict__ tau, int tie_knn,
-                                                     uint64_t *__restrict__ keys_out) {
+                                                     uint64_t *__restrict__ keys_out,
+                                                     const uint32_t *__restrict__ only_if = nullptr) {
+  if (only_if && *only_if == 0u) return;                 // launched behind the pair-list kernels: runs only if their list overflowed
   const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (b >= count) return;
@@ -248,7 +250,9 @@ template <int K>
 __global__ __launch_bounds__(256) void k_topk_merge(int64_t count, const TopkSpan *__restrict__ span,
                                                     const uint64_t *__restrict__ partial,
                                                     const uint32_t *__restrict__ counter,
-                                                    uint64_t *__restrict__ keys_out) {
+                                                    uint64_t *__restrict__ keys_out,
+                                                    unsigned long long *__restrict__ pairs_total = nullptr) {
+  if (pairs_total && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(pairs_total, static_cast<unsigned long long>(counter[0]));
   if (counter[1]) return;
   const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;

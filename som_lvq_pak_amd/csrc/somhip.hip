@@ -116,7 +116,6 @@ struct somhip_engine {
   uint64_t samples_searched = 0;
   uint64_t lvq_batches = 0, lvq_samples = 0;   // exact batched LVQ: rescans and samples
   uint64_t lvq_stop_list = 0, lvq_stop_cache = 0, lvq_cycles[4] = {0, 0, 0, 0};   // batches ended by an exhausted candidate list / a full cache
-  uint64_t topk_pairs = 0;                        // (sample, row group) pairs the exact top-k re-rank evaluated (64 rows each)
   int64_t lvq_batch_hint = 256;                   // batch size the exact LVQ engine starts its next call with
   uint64_t lvq_components = 0, lvq_largest = 0;   // independent components walked, and the sum of the largest one's size per batch
   // ring of pinned host staging buffers for per-batch scalars (H2D without a host sync)
@@ -139,6 +138,8 @@ struct somhip_engine {
   std::vector<somhip_codebook *> codebooks;
   std::vector<somhip_dataset *> datasets;
   bool lvq_apply_attr_set = false;             // hipFuncSetAttribute(k_lvq_batch_apply, ...) done on this device
+  LvqCtl *lvq_hctl = nullptr;                  // pinned: read-backs of the LVQ batch loop's control block, one per batch in flight
+  hipEvent_t lvq_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 static int engine_scratch(somhip_engine *e, int slot, size_t bytes, void **out) {
@@ -233,8 +234,8 @@ extern "C" int somhip_engine_create(int device, somhip_engine **out) try {
   auto init = [&]() -> int {
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     if (const char *ts = getenv("SOMHIP_TAU_SCALE")) { double v = atof(ts); if (v >= 1.0) e->tau_scale = v; }
-    HIPCHK(hipMalloc((void **)&e->d_stats, (8 + 128 + 8 + 1) * sizeof(unsigned long long)));   // + 64 {rows, pairs} update counters + 8 gemm-walk counters + level-2 pairs
-    HIPCHK(hipMemset(e->d_stats, 0, (8 + 128 + 8 + 1) * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&e->d_stats, (8 + 128 + 8 + 2) * sizeof(unsigned long long)));   // + 64 {rows, pairs} update counters + 8 gemm-walk counters + level-2 pairs + top-k pairs
+    HIPCHK(hipMemset(e->d_stats, 0, (8 + 128 + 8 + 2) * sizeof(unsigned long long)));
     if (const char *um = getenv("SOMHIP_UPDATE_MODE")) e->update_mode = strcmp(um, "gemm") == 0 ? SOMHIP_UPDATE_GEMM : SOMHIP_UPDATE_EXACT;
     return 0;
   };
@@ -259,6 +260,8 @@ extern "C" void somhip_engine_destroy(somhip_engine *e) try {
     if (e->pin_buf[i]) (void)hipHostFree(e->pin_buf[i]);
     if (e->pin_ev[i]) (void)hipEventDestroy(e->pin_ev[i]);
   }
+  if (e->lvq_hctl) (void)hipHostFree(e->lvq_hctl);
+  for (int i = 0; i < 8; i++) if (e->lvq_ev[i]) (void)hipEventDestroy(e->lvq_ev[i]);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 } ABI_CATCH_VOID(somhip_engine_destroy)
@@ -303,7 +306,11 @@ extern "C" int somhip_lvq_stats(somhip_engine *e, uint64_t out[12]) try {
   if (!e || !out) return fail("somhip_lvq_stats: null argument");
   out[0] = e->lvq_batches; out[1] = e->lvq_samples; out[2] = e->lvq_stop_list; out[3] = e->lvq_stop_cache;
   for (int k = 0; k < 4; k++) out[4 + k] = e->lvq_cycles[k];
-  out[8] = e->lvq_components; out[9] = e->lvq_largest; out[10] = e->topk_pairs; out[11] = 0;
+  unsigned long long pairs = 0;                            // counted on the device (the top-k search does not wait for the host)
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipMemcpyAsync(&pairs, e->d_stats + 8 + 128 + 8 + 1, sizeof pairs, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  out[8] = e->lvq_components; out[9] = e->lvq_largest; out[10] = pairs; out[11] = 0;
   return 0;
 } ABI_CATCH(somhip_lvq_stats)
 extern "C" int somhip_timing_enable(somhip_engine *e, int on) try {
