@@ -114,10 +114,12 @@ __global__ __launch_bounds__(256) void k_lvq_amax(const uint64_t *__restrict__ c
       if (!(t >= 0.0f && t < 1.0f)) s_bad = 1;
       m = fmaxf(m, t);
     }
-  s_m[threadIdx.x] = m;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, WAVE));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int i = 1; i < 256; i++) m = fmaxf(m, s_m[i]);
+    for (int i = 1; i < 4; i++) m = fmaxf(m, s_m[i]);
     *amax = (s_bad || !(clamp >= 0.0f && clamp < 1.0f)) ? -1.0f : fmaxf(m, clamp);
   }
 }
@@ -244,34 +246,80 @@ __global__ __launch_bounds__(LVQ_BMAX) void k_lvq_components(const uint32_t *__r
     __syncthreads();                                      // everyone has read the flag before the next round clears it
     if (!changed) break;
   }
-  // sizes, rank of each root by (size descending, root ascending), position of each sample inside its component
-  if (j < count) atomicAdd(&s_size[s_label[j]], 1);
+  // ---- sizes; the roots in sample order; rank of each root by (size descending, root ascending); start offsets;
+  // position of each sample inside its component (samples of a component stay in iteration order).  All of it in
+  // wave-parallel steps: the serial versions (one thread's prefix sum over the components, a 1024-trip loop per
+  // root and per sample) were most of this kernel's time.
+  const int lane = j & 63, wave = j >> 6;
+  __shared__ int32_t s_wtot[LVQ_BMAX / 64 + 1], s_rid[LVQ_BMAX], s_rsize[LVQ_BMAX];
+  const int l = j < count ? s_label[j] : -1;
+  if (j < count) atomicAdd(&s_size[l], 1);
   __syncthreads();
-  const bool root = j < count && s_label[j] == j;
-  int rank = 0;
-  if (root) {
-    const int mine = s_size[j];
-    for (int i = 0; i < count; i++)
-      if (s_label[i] == i && (s_size[i] > mine || (s_size[i] == mine && i < j))) rank++;
-    atomicAdd(&s_ncomp, 1);
+  const bool root = j < count && l == j;
+  {
+    const unsigned long long bal = __ballot(root);
+    if (lane == 0) s_wtot[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; w++) before += s_wtot[w];
+    if (j == 0) { int t = 0; for (int w = 0; w < LVQ_BMAX / 64; w++) t += s_wtot[w]; s_ncomp = t; }
+    const int r = before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (root) { s_rid[r] = j; s_rsize[r] = s_size[j]; }
   }
-  s_rank[j] = root ? rank : -1;
   __syncthreads();
-  if (root) s_start[rank + 1] = s_size[j];                // sizes first; prefix-summed by thread 0 below
-  __syncthreads();
-  if (j == 0) {
-    int run = 0;
-    s_start[0] = 0;
-    for (int c = 0; c < s_ncomp; c++) { const int sz = s_start[c + 1]; s_start[c + 1] = run + sz; run += sz; }
-  }
-  __syncthreads();
-  if (j < count) {
-    const int l = s_label[j], c = s_rank[l];
-    int pos = 0;
-    for (int i = 0; i < j; i++) pos += s_label[i] == l;
-    comp_samples[s_start[c] + pos] = j;
-  }
   const int nc = s_ncomp;
+  // thread r < nc: the r-th root; its rank among the roots
+  int my_rank = 0;
+  if (j < nc) {
+    const int mine = s_rsize[j];
+    for (int k = 0; k < nc; k++) {
+      const int sk = s_rsize[k];
+      my_rank += (sk > mine || (sk == mine && k < j)) ? 1 : 0;
+    }
+    s_rank[s_rid[j]] = my_rank;
+  }
+  __syncthreads();
+  // start[]: exclusive prefix sum of the sizes in rank order (thread = rank)
+  {
+    if (j < nc) s_start[1 + my_rank] = s_rsize[j];       // scatter, then scan in place
+    if (j == 0) s_start[0] = 0;
+    __syncthreads();
+    int v = (j < nc) ? s_start[1 + j] : 0;                // size of the component of rank j
+    int inc = v;                                          // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) s_wtot[wave] = inc;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; w++) before += s_wtot[w];
+    if (j < nc) s_start[1 + j] = before + inc;
+  }
+  // position inside the component: earlier samples with the same label = those of earlier waves (counted per wave
+  // and label into the LDS that held the adjacency rows) + those of lower lanes in this wave
+  {
+    int32_t *s_cnt = reinterpret_cast<int32_t *>(s_adjrows);      // [wave][label], 16 x count ints (<= 64 KiB of the 128)
+    __syncthreads();
+    for (int e = j; e < (LVQ_BMAX / 64) * count; e += LVQ_BMAX) s_cnt[e] = 0;
+    __syncthreads();
+    int prior = 0, wave_total = 0;                         // lower lanes / all lanes of this wave with my label
+    for (int k = 0; k < 64; k++) {                         // (in uniform control flow: every lane's label is read)
+      const int lk = __builtin_amdgcn_readlane(l, k);
+      wave_total += lk == l ? 1 : 0;
+      prior += (lk == l && k < lane) ? 1 : 0;
+    }
+    if (j < count && prior == 0) s_cnt[wave * count + l] = wave_total;   // the first lane of each label
+    __syncthreads();
+    if (j < count) {
+      int pos = prior;
+      for (int w = 0; w < wave; w++) pos += s_cnt[w * count + l];
+      comp_samples[s_start[s_rank[l]] + pos] = j;
+    }
+  }
+  __syncthreads();
   if (j == 0) { out->ncomp = nc; out->pad = 0; for (int c = 0; c < 4; c++) out->cycles[c] = 0; }
   if (j <= nc) out->start[j] = s_start[j];
 }
