@@ -315,6 +315,48 @@ __global__ __launch_bounds__(256) void k_group_min(int64_t ngroups, int64_t bpad
   }
 }
 
+// The K-th smallest group minimum per sample (same output convention as k_group_min: the ordered image of the
+// float): the two-level pre-filter of a top-K search measures its level-1 window from this value instead of the
+// minimum.  Workgroup = 32 samples x 8 slices of the groups (coalesced over samples); each thread keeps the K
+// smallest of its slice, thread (sample, slice 0) merges the eight lists.  Fewer than K groups: 3.4e38 (all pass).
+template <int K>
+__global__ __launch_bounds__(256) void k_group_kth(int64_t ngroups, int64_t bpad, const float *__restrict__ wmin,
+                                                   uint32_t *__restrict__ gkth) {
+  __shared__ float s_k[8][K][32];
+  const int tid = threadIdx.x, bx = tid & 31, gy = tid >> 5;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 32 + bx;
+  float mine[K];
+#pragma unroll
+  for (int t = 0; t < K; t++) mine[t] = 3.4e38f;
+  if (b < bpad)
+    for (int64_t g = gy; g < ngroups; g += 8) {
+      float v = wmin[g * bpad + b];
+#pragma unroll
+      for (int t = 0; t < K; t++) {                      // sorted insertion
+        const float lo = fminf(mine[t], v);
+        v = fmaxf(mine[t], v);
+        mine[t] = lo;
+      }
+    }
+#pragma unroll
+  for (int t = 0; t < K; t++) s_k[gy][t][bx] = mine[t];
+  __syncthreads();
+  if (gy == 0 && b < bpad) {
+    for (int k = 1; k < 8; k++)
+#pragma unroll
+      for (int u = 0; u < K; u++) {
+        float v = s_k[k][u][bx];
+#pragma unroll
+        for (int t = 0; t < K; t++) {
+          const float lo = fminf(mine[t], v);
+          v = fmaxf(mine[t], v);
+          mine[t] = lo;
+        }
+      }
+    gkth[b] = float_to_ordered(mine[K - 1]);
+  }
+}
+
 // K2s: rows of every group within tau of the sample's global minimum -> (sample, row) pairs.
 // Same workgroup shape as K2m (32 samples x a chunk of groups), so the whole wmin matrix is
 // read by thousands of workgroups at once instead of 128 long-running ones.
