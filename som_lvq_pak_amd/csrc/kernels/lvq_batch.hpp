@@ -74,7 +74,7 @@ __device__ __forceinline__ float lvq_sq(float c, float x) { const float t = c - 
 __global__ __launch_bounds__(256) void k_lvq_sample_rho(const float *__restrict__ rows, int64_t n_rows, int d,
                                                         int64_t first, int count, const uint64_t *__restrict__ cand,
                                                         float amax_host, const float *__restrict__ amax_dev,
-                                                        float *__restrict__ rho) {
+                                                        float *__restrict__ rho, float *__restrict__ xnorm = nullptr) {
   const float amax = amax_dev ? *amax_dev : amax_host;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (j >= count) return;
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void k_lvq_sample_rho(const float *__restrict_
       if (static_cast<double>(r) < v) r = __uint_as_float(__float_as_uint(r) + 1);
     }
     rho[j] = r;
+    if (xnorm) xnorm[j] = s;                               // ||x_j||^2 as summed here (k_lvq_pair_adj_mfma)
   }
 }
 
@@ -198,6 +199,75 @@ __global__ __launch_bounds__(256) void k_lvq_pair_adj(const float *__restrict__ 
     for (int b = 0; b < 32; b++) { w |= static_cast<uint32_t>(sadj[r][32 * h + b]) << b; wt |= static_cast<uint32_t>(sadj[32 * h + b][r]) << b; }
     if (tj * 64 + r < LVQ_BMAX) adj[static_cast<int64_t>(tj * 64 + r) * LVQ_AW + ti * 2 + h] = w;
     if (ti != tj && ti * 64 + r < LVQ_BMAX) adj[static_cast<int64_t>(ti * 64 + r) * LVQ_AW + tj * 2 + h] = wt;
+  }
+}
+
+// The same relation with the pairwise distances in Gram form on the fp32 matrix pipe: d^2(j, i) = ||x_j||^2 +
+// ||x_i||^2 - 2 <x_j, x_i>, the inner products of a 64 x 64 tile of pairs by v_mfma_f32_32x32x2_f32 (one 32 x 32
+// sub-tile per wave, operands straight from the row-major data: per 8 dims one float4 per lane and operand, element
+// e of it feeding MFMA e -- lanes 0-31 carry dims k0 + e, lanes 32-63 dims k0 + 4 + e, the same for both operands).
+// (*) only has to be decided CONSERVATIVELY (an extra edge merges two components, which costs parallelism, never
+// exactness): with u = 2^-24 the computed value differs from the real d^2 by at most (3 d + 16) u (n_j + n_i)
+// (fp32 products, fp32 accumulation in any order, the two wave-summed norms), so "computed <= (rho_j + rho_i)^2
+// (1 + 2^-10) + 8 (d + 8) u (n_j + n_i)" holds for every pair that satisfies (*).  The inner products are
+// bit-symmetric in (j, i) (same products, same order), hence so is the matrix; every tile of it is computed
+// (no mirror writes).  Needs d % 8 == 0; other shapes use k_lvq_pair_adj.
+__global__ __launch_bounds__(256) void k_lvq_pair_adj_mfma(const float *__restrict__ rows, int64_t n_rows, int d,
+                                                           int64_t first, int count, const float *__restrict__ rho,
+                                                           const float *__restrict__ xnorm, uint32_t *__restrict__ adj) {
+  const int tj = blockIdx.y, ti = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
+  const int j = tj * 64 + wr * 32 + l31, i = ti * 64 + wc * 32 + l31;      // this lane's row of operand A / B
+  const float *pa = rows + ((first + (j < count ? j : count - 1)) % n_rows) * static_cast<int64_t>(d) + 4 * half;
+  const float *pb = rows + ((first + (i < count ? i : count - 1)) % n_rows) * static_cast<int64_t>(d) + 4 * half;
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; v++) acc[v] = 0.0f;
+  int k0 = 0;
+  for (; k0 + 32 <= d; k0 += 32) {                         // 32 dims: eight loads in flight, then 16 MFMAs
+    float4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      a[u] = *reinterpret_cast<const float4 *>(pa + k0 + 8 * u);
+      b[u] = *reinterpret_cast<const float4 *>(pb + k0 + 8 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+    }
+  }
+  for (; k0 < d; k0 += 8) {
+    const float4 a = *reinterpret_cast<const float4 *>(pa + k0), b = *reinterpret_cast<const float4 *>(pb + k0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  // register v of the tile: row (v / 4) * 8 + half * 4 + v % 4 (a sample j), column l31 (sample i)
+  const bool i_ok = i < count;
+  const double ni = i_ok ? static_cast<double>(xnorm[i]) : 0.0, ri = i_ok ? static_cast<double>(rho[i]) : 0.0;
+  const double slack_unit = 8.0 * (d + 8) * 5.9604644775390625e-08;
+  const int word = ti * 2 + wc;
+#pragma unroll
+  for (int v = 0; v < 16; v++) {
+    const int jr = tj * 64 + wr * 32 + (v >> 2) * 8 + half * 4 + (v & 3);
+    bool on = false;
+    if (jr < count && i_ok && jr != i) {
+      const double nj = static_cast<double>(xnorm[jr]), rj = static_cast<double>(rho[jr]);
+      const double d2 = nj + ni - 2.0 * static_cast<double>(acc[v]);
+      const double r = rj + ri;
+      on = d2 <= r * r * (1.0 + 1.0 / 1024.0) + slack_unit * (nj + ni);      // (rho = +inf: always)
+    }
+    const unsigned long long bal = __ballot(on);
+    const int j0 = tj * 64 + wr * 32 + (v >> 2) * 8 + (v & 3);               // the row of half 0; half 1: + 4
+    if (lane == 0) {
+      if (j0 < LVQ_BMAX) adj[static_cast<int64_t>(j0) * LVQ_AW + word] = static_cast<uint32_t>(bal);
+      if (j0 + 4 < LVQ_BMAX) adj[static_cast<int64_t>(j0 + 4) * LVQ_AW + word] = static_cast<uint32_t>(bal >> 32);
+    }
   }
 }
 
