@@ -166,7 +166,9 @@ __global__ __launch_bounds__(256) void k_topk_select(CbView cb, int64_t count, i
                                                      const float *__restrict__ wmin,
                                                      const float *__restrict__ tau, uint32_t cap,
                                                      uint2 *__restrict__ pairs, TopkSpan *__restrict__ span,
-                                                     uint32_t *__restrict__ counter /* [0] fill, [1] overflow */) {
+                                                     uint32_t *__restrict__ counter /* [0] fill, [1] overflow */,
+                                                     uint32_t *__restrict__ gcnt = nullptr, uint2 *__restrict__ glist = nullptr,
+                                                     uint32_t cap_g = 0) {
   const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (b >= count) return;
@@ -214,8 +216,90 @@ __global__ __launch_bounds__(256) void k_topk_select(CbView cb, int64_t count, i
     const int64_t gl = gb + lane;
     const bool q = gl < cb.ngroups && wmin[gl * bpad + b] <= thr;
     const unsigned long long ball = __ballot(q);
-    if (q) pairs[at + __popcll(ball & ((1ull << lane) - 1))] = make_uint2(static_cast<uint32_t>(b), static_cast<uint32_t>(gl));
+    if (q) {
+      const uint32_t p = at + __popcll(ball & ((1ull << lane) - 1));
+      pairs[p] = make_uint2(static_cast<uint32_t>(b), static_cast<uint32_t>(gl));
+      if (gcnt) {                                        // the same pair filed under its group (k_topk_pairs_bygroup)
+        const uint32_t slot = atomicAdd(&gcnt[gl], 1u);
+        if (slot < cap_g) glist[static_cast<size_t>(gl) * cap_g + slot] = make_uint2(static_cast<uint32_t>(b), p);
+        else atomicMax(counter + 1, 1u);
+      }
+    }
     at += __popcll(ball);
+  }
+}
+
+// (2) by row group: one workgroup per group takes the samples filed under it four at a time per wave -- the group's
+// tile (64 rows x d, 256 KiB at d = 1024) is streamed once per four samples instead of once per pair, and the waves
+// of a workgroup read it together.  The distance of every (row, sample) is the reference's sum in the reference's
+// order, as in k_topk_pairs; the results go to the same per-pair slots, so (3) does not care which of the two ran.
+template <int K>
+__global__ __launch_bounds__(256) void k_topk_pairs_bygroup(CbView cb, const float *__restrict__ rows, int64_t n_rows,
+                                                            int64_t first, int tie_knn, const uint32_t *__restrict__ gcnt,
+                                                            const uint2 *__restrict__ glist, uint32_t cap_g,
+                                                            const uint32_t *__restrict__ counter,
+                                                            uint64_t *__restrict__ partial /* [pair][K] */) {
+  if (counter[1]) return;
+  const int64_t g = blockIdx.x;
+  const uint32_t n = gcnt[g] < cap_g ? gcnt[g] : cap_g;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int64_t row = g * WAVE + lane;
+  const uint32_t grow = unit_of_row(cb, row);
+  extern __shared__ float4 s_topk_x[];                     // [wave][4 samples][d4]: the samples' rows of the pass in hand
+  float4 *sx = s_topk_x + static_cast<size_t>(wave) * 4 * cb.d4;
+  constexpr int U = 8;                                   // tile chunks per register buffer (two buffers, as in K3's row stream)
+  // (a crowded group -- a class centre draws hundreds of a batch's samples -- is spread over the gridDim.y workgroups of its row)
+  for (uint32_t base = (blockIdx.y * 4u + static_cast<uint32_t>(wave)) * 4u; base < n; base += 16u * gridDim.y) {
+    const uint32_t m = n - base < 4u ? n - base : 4u;
+    uint32_t slot[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const uint2 en = glist[static_cast<size_t>(g) * cap_g + base + (static_cast<uint32_t>(s) < m ? s : 0)];
+      slot[s] = en.y;
+      const float4 *x = reinterpret_cast<const float4 *>(rows + ((first + en.x) % n_rows) * cb.d);
+      for (int q = lane; q < cb.d4; q += WAVE) sx[s * cb.d4 + q] = x[q];
+    }
+    // (each wave reads back only what it wrote: no barrier, the LDS operations of a wave complete in order)
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto chunk = [&](int q, const float4 c) {
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const float4 xs = sx[s * cb.d4 + q];
+        acc[s] = sq_acc(acc[s], c.x, xs.x);
+        acc[s] = sq_acc(acc[s], c.y, xs.y);
+        acc[s] = sq_acc(acc[s], c.z, xs.z);
+        acc[s] = sq_acc(acc[s], c.w, xs.w);
+      }
+    };
+    float4 bufA[U], bufB[U];
+    const int nfull = (cb.d4 / (2 * U)) * (2 * U), last = cb.d4 - 1;
+    if (nfull > 0) {
+#pragma unroll
+      for (int u = 0; u < U; u++) bufA[u] = *tile_ptr(cb, g, u, lane);
+      for (int qb = 0; qb < nfull; qb += 2 * U) {
+#pragma unroll
+        for (int u = 0; u < U; u++) bufB[u] = *tile_ptr(cb, g, qb + U + u, lane);
+#pragma unroll
+        for (int u = 0; u < U; u++) chunk(qb + u, bufA[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int q = qb + 2 * U + u; bufA[u] = *tile_ptr(cb, g, q < last ? q : last, lane); }
+#pragma unroll
+        for (int u = 0; u < U; u++) chunk(qb + U + u, bufB[u]);
+      }
+    }
+    for (int q = nfull; q < cb.d4; q++) chunk(q, *tile_ptr(cb, g, q, lane));
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      if (static_cast<uint32_t>(s) >= m) break;
+      uint64_t k = row < cb.n ? make_key(acc[s], tie_knn ? ~grow : grow) : KEY_NONE;
+#pragma unroll
+      for (int t = 0; t < K; t++) {
+        const uint64_t best = wave_min_u64_dpp(k);
+        if (lane == 0) partial[static_cast<size_t>(slot[s]) * K + t] = best;
+        if (k == best) k = KEY_NONE;
+      }
+    }
   }
 }
 
