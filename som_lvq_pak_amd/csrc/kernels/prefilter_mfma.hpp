@@ -903,6 +903,7 @@ __global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t coun
 // level 2: the three-product GEMM of one row group against tiles of 32 of ITS surviving samples; one wave per tile,
 // operands straight from global memory (each lane loads the 16-byte pieces the MFMA wants from it: for B the piece
 // of its own gathered sample).  Writes wmin / wmask of the (group, sample) pairs it covers.
+template <int DEPTH>                   // k-steps whose operands are requested together
 __global__ __launch_bounds__(256) void k_dist_l2(CbView cb, int d8, const uint4 *__restrict__ chi, const uint4 *__restrict__ clo,
                                                  const uint4 *__restrict__ xhi, const uint4 *__restrict__ xlo,
                                                  const float *__restrict__ cn, const float *__restrict__ tau, int64_t bpad,
@@ -927,18 +928,18 @@ __global__ __launch_bounds__(256) void k_dist_l2(CbView cb, int d8, const uint4 
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
     // k-step ks uses k-blocks 2 ks + half.  The loop is a chain of global-memory round trips (nothing else hides them:
-    // a group often has a single tile), so the operands of FOUR k-steps are requested together: a quarter of the trips.
+    // a group often has a single tile), so the operands of DEPTH k-steps are requested together: 1 / DEPTH of the trips.
     const int nks = d8 / 2;                              // a multiple of 2 (the host takes this path for d8 % 4 == 0)
-    for (int ks0 = 0; ks0 < nks; ks0 += 4) {
-      uint4 rA0[4], rA1[4], rL0[4], rL1[4], rBH[4], rBL[4];
+    for (int ks0 = 0; ks0 < nks; ks0 += DEPTH) {
+      uint4 rA0[DEPTH], rA1[DEPTH], rL0[DEPTH], rL1[DEPTH], rBH[DEPTH], rBL[DEPTH];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < DEPTH; u++) {
         const int o = 2 * (ks0 + u < nks ? ks0 + u : nks - 1);
         rA0[u] = pa[o * 64]; rA1[u] = pa[o * 64 + 32]; rL0[u] = pl[o * 64]; rL1[u] = pl[o * 64 + 32];
         rBH[u] = pxh[o * 32]; rBL[u] = pxl[o * 32];
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < DEPTH; u++) {
         if (ks0 + u < nks) {
           const bf16x8 a0 = __builtin_bit_cast(bf16x8, rA0[u]), a1 = __builtin_bit_cast(bf16x8, rA1[u]);
           const bf16x8 l0 = __builtin_bit_cast(bf16x8, rL0[u]), l1 = __builtin_bit_cast(bf16x8, rL1[u]);

@@ -354,6 +354,28 @@ def test_topk_behind_the_mfma_prefilter(eng, E, oracle, knn, rule, n, d, m):
     assert np.array_equal(bits(gd), bits(want_d))
 
 
+def test_top8_two_level_and_by_group_equal_the_plain_paths(eng, E, oracle):
+    """The top-8 search of a big codebook (>= 512 row groups): two-level pre-filter + re-rank by row group (the
+    defaults there) against the one-level pre-filter, the per-pair re-rank, and find_winner_knn itself; clustered
+    codes with exact duplicates, so that ties and crowded groups occur."""
+    n, d, m = 40000, 64, 1024
+    x, _ = synth(77, m, d, k=6, spread=2.0)
+    rs = np.random.RandomState(5)
+    codes = (x[rs.randint(0, m, n)] + 0.05 * rs.standard_normal((n, d))).astype(np.float32)
+    codes[n // 2:n // 2 + 50] = codes[:50]
+    want_i, want_d, _ = oracle.winners(codes, x, 8, True)
+    cb, ds = E.Codebook(eng, codes), E.Dataset(eng, x)
+    for env in ({}, {"SOMHIP_TOPK_ONE_LEVEL": "1"}, {"SOMHIP_TOPK_BYPAIR": "1"}, {"SOMHIP_TOPK_ONE_LEVEL": "1", "SOMHIP_TOPK_BYPAIR": "1"}):
+        os.environ.update(env)
+        try:
+            gi, gd, _ = E.find_winners(cb, ds, knn=8, tie=E.TIE_KNN)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert np.array_equal(gi, want_i), env
+        assert np.array_equal(bits(gd), bits(want_d)), env
+
+
 # --------------------------------------------------------------------------- lvq*_training
 LVQ_CASES = [("lvq1", 1, {}), ("olvq1", 2, {}), ("lvq2", 3, {"winlen": 0.3}),
              ("lvq3", 4, {"winlen": 0.3, "epsilon": 0.1}), ("lvq1_invt", 1, {"alpha_type": 2})]
@@ -403,9 +425,13 @@ def _lvq_both_engines(eng, E, oracle, kind, codes, clab, x, lab, length, alpha, 
     """exact batched engine (default) and one-launch-per-iteration engine against the oracle"""
     oc, ol, oi, od = oracle.lvq_train(kind, codes, clab, x, lab, length, alpha, **kw)
     stats = {}
-    for mode in ("batched", "batched_serial", "batched_mfma_topk", "online"):
+    for mode in ("batched", "batched_serial", "batched_mfma_topk", "batched_sync", "batched_pairs_valu", "online"):
         if mode == "online":
             os.environ["SOMHIP_LVQ_ONLINE"] = "1"
+        if mode == "batched_sync":
+            os.environ["SOMHIP_LVQ_SYNC"] = "1"              # every batch's verdict read back before the next (round 2's first loop)
+        if mode == "batched_pairs_valu":
+            os.environ["SOMHIP_LVQ_PAIRS_VALU"] = "1"        # relation (*) from direct-form distances instead of the Gram form
         if mode == "batched_mfma_topk":
             os.environ["SOMHIP_TOPK_MFMA"] = "1"
         if mode == "batched_serial":
@@ -420,6 +446,8 @@ def _lvq_both_engines(eng, E, oracle, kind, codes, clab, x, lab, length, alpha, 
             os.environ.pop("SOMHIP_LVQ_ONLINE", None)
             os.environ.pop("SOMHIP_TOPK_MFMA", None)
             os.environ.pop("SOMHIP_LVQ_SERIAL", None)
+            os.environ.pop("SOMHIP_LVQ_SYNC", None)
+            os.environ.pop("SOMHIP_LVQ_PAIRS_VALU", None)
         assert np.array_equal(ti, oi), mode
         assert np.array_equal(bits(td), bits(od)), mode
         assert np.array_equal(bits(cb.download()), bits(oc)), mode
@@ -430,6 +458,9 @@ def _lvq_both_engines(eng, E, oracle, kind, codes, clab, x, lab, length, alpha, 
     assert stats["batched"]["samples"] == length
     assert stats["batched_serial"]["components"] == stats["batched_serial"]["batches"]      # one walk per batch
     assert stats["batched"]["components"] >= stats["batched"]["batches"]
+    # (the two loops size their batches differently after a stop, so only the totals must agree)
+    assert stats["batched"]["samples"] == stats["batched_sync"]["samples"] == length
+    assert (stats["batched"]["stop_list"] > 0) == (stats["batched_sync"]["stop_list"] > 0)
     return stats["batched_serial"], stats["batched"]
 
 

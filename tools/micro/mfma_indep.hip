@@ -1,10 +1,11 @@
-// Do INDEPENDENT VALU / LDS-read / readlane instructions issued between fp32 MFMAs (v_mfma_f32_32x32x2_f32) of the same
-// wave run in the shadow of the matrix pipe?  Per loop iteration: 8 MFMAs on 8 accumulators and NV other
+// Do INDEPENDENT VALU / LDS-read / readlane instructions issued between MFMAs of the same wave run in the shadow of the
+// matrix pipe?  First table: fp32 MFMAs (v_mfma_f32_32x32x2_f32); second: bf16 (v_mfma_f32_32x32x16_bf16, -DBF16 build).  Per loop iteration: 8 MFMAs on 8 accumulators and NV other
 // instructions, interleaved by sched_group_barrier.  KIND 0: v_mul on registers nobody else reads; 1: v_readlane +
 // v_mul; 2: ds_read_b128.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int NM, int NV, int KIND>
 __global__ __launch_bounds__(256, 2) void k(float *out, int iters, float na) {
   __shared__ float4 lds[1024];
@@ -15,9 +16,17 @@ __global__ __launch_bounds__(256, 2) void k(float *out, int iters, float na) {
   lds[threadIdx.x] = make_float4(v[0], v[1], v[2], v[3]);
   __syncthreads();
   const float a0 = threadIdx.x * 0.01f, b0 = threadIdx.x * 0.02f;
+  bf16x8 ab, bb;
+  for (int i = 0; i < 8; i++) { ab[i] = (__bf16)(a0 + i); bb[i] = (__bf16)(b0 - i); }
   for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int m = 0; m < NM; m++) acc[m & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[m & 7], 0, 0, 0);
+    for (int m = 0; m < NM; m++) {
+#ifdef BF16
+      acc[m & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, acc[m & 7], 0, 0, 0);
+#else
+      acc[m & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[m & 7], 0, 0, 0);
+#endif
+    }
 #pragma unroll
     for (int j = 0; j < NV; j++) {
       if (KIND == 0) v[j & 7] = v[j & 7] * na;
