@@ -7,16 +7,18 @@ alpha 0.05 linear, radius 128 -> 1, over 10 000 000 vectors of the seeded Gaussi
 (`-din gen:k=256,dim=512,n=10000000,seed=3456`, made in HBM by somhip_dataset_generate; initial map =
 `randinit -rand 7` from the stream's bounding box).  One stream for the GPU leg, the CPU baseline and the C tools.
 
-A "step" is one mini-batch of --batch (4096) vectors through the whole hot path: exact best-matching-unit
-search for every vector + the in-order neighbourhood update.  The timed region is EXACTLY --steps such steps,
-taken at evenly spaced positions of the real 10 M-iteration schedule (step k runs iterations
-[k*S, k*S + batch), S = schedule length / steps rounded down to whole batches), so the radius sweeps its whole
-range inside the timed region and every step costs what it costs at that point of the real run.
+A "step" is one mini-batch through the whole hot path: exact best-matching-unit search for every vector of the
+batch + the in-order neighbourhood update.  Batch sizes are the engine's own schedule (somhip.h SOMHIP_BATCH_AUTO,
+somhip_som_auto_batch: 16384 vectors over the first three quarters of the run, 8192 after; `--batch B` fixes one
+size).  The timed region is EXACTLY --steps such batches of the real 10 M-iteration schedule, evenly spread over
+it (step k = the batch that holds iteration k * length / steps), so the radius sweeps its whole range inside the
+timed region and every step costs what it costs at that point of the real run; `value` = vectors of those batches
+/ time.
 
 Conformity (north_star: "qerror within 1e-4 of the CPU reference").  The reference is strictly online
 (som_rout.c:600-662); the engine's batch = 1 path is bit-exact with it but HBM-bound (27 k vectors/s).  The
 mini-batch schedule is a different algorithm, so its result is CHECKED: after the timed region the whole
-10 M-vector run is made with the same schedule (about 5 s) and its final qerror is compared with the online
+10 M-vector run is made with the same schedule (about 2 s) and its final qerror is compared with the online
 engine's on the same stream, same initial map (a 370 s run, recorded once in profiles/r02_c4_full_length.json --
 both engines are bit-deterministic, so that number is a constant of the workload; `--online-full` re-measures
 it live).  `qerror_check.pass` gates `value`: if the check fails, `value` falls back to the online engine's rate.
@@ -57,7 +59,9 @@ def parse():
     ap.add_argument("--config", default="c4", choices=["c4", "c3", "c5"],
                     help="c4 = BASELINE configs[3] (SOM 256x256x512, the headline); c3 = configs[2] (OLVQ1 10k x 256); "
                          "c5 = configs[4] shape (LVQ3 100k x 1024)")
-    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=-1,
+                    help="vectors per mini-batch; -1 (default) = the engine's own schedule (SOMHIP_BATCH_AUTO: 16384 over the first "
+                         "three quarters of the run, 8192 after)")
     ap.add_argument("--xdim", type=int, default=256)
     ap.add_argument("--ydim", type=int, default=256)
     ap.add_argument("--dim", type=int, default=512)
@@ -151,12 +155,14 @@ def bench_som(a):
     N = xdim * ydim
     radius = a.radius if a.radius is not None else max(xdim, ydim) / 2.0
     seed, kcent, init_seed = 3456, 256, 7
-    nbatches = L // B
-    if nbatches < 1:
-        raise SystemExit("--length must be at least one batch")
-    stride = max(1, nbatches // max(K, 1)) * B        # timed step k starts at iteration k * stride
-    if (K - 1) * stride + B > L:
-        raise SystemExit("--steps %d x --batch %d does not fit a schedule of %d iterations" % (K, B, L))
+    auto_b = B == -1
+    if not auto_b:
+        nbatches = L // B
+        if nbatches < 1:
+            raise SystemExit("--length must be at least one batch")
+        stride = max(1, nbatches // max(K, 1)) * B        # timed step k starts at iteration k * stride
+        if (K - 1) * stride + B > L:
+            raise SystemExit("--steps %d x --batch %d does not fit a schedule of %d iterations" % (K, B, L))
 
     # ---- the stream, resident in HBM before any timing; identical on every rank (counter-based generator) ----
     eng = E.Engine(local)
@@ -178,8 +184,20 @@ def bench_som(a):
         layout = "contiguous row blocks /%d" % world
     lib = eng.lib
     gshard = sharded.GpuShard(eng, cb, ds, lambda: SomParams(L, a.alpha, radius, E.ALPHA_LINEAR, 0, 0, B, 0, 0, 0),
-                              max(B, 8192))
+                              max(B, 16384))
     ssom = sharded.ShardedSom(gshard, B, L)
+    # the timed steps: K batches of the schedule, evenly spread over it -- (first iteration, vectors) each
+    if auto_b:
+        steps_at = []
+        for k in range(K):
+            st, ln = E.som_auto_batch(lib, L, (k * L) // max(K, 1))
+            if not steps_at or st != steps_at[-1][0]:
+                steps_at.append((st, ln))
+        if len(steps_at) != K:
+            raise SystemExit("--steps %d: more steps than batches in a schedule of %d iterations" % (K, L))
+    else:
+        steps_at = [(k * stride, B) for k in range(K)]
+    vectors_timed = sum(ln for _, ln in steps_at)
 
     def barrier():
         eng.sync()
@@ -207,8 +225,8 @@ def bench_som(a):
         return float(E.qerror_sum(diffs) / np.float32(ne)), ne
 
     # ---- warmup on the first W steps of the timed sequence, then the initial map again ----
-    for k in range(min(W, K)):
-        ssom.step(k * stride, k * stride, B)
+    for st, ln in steps_at[:min(W, K)]:
+        ssom.step(st, st, ln)
     eng.sync()
     cb.upload(init[mine])
 
@@ -220,8 +238,8 @@ def bench_som(a):
     stats_before = eng.scan_stats()
     barrier()
     t0 = time.perf_counter()
-    for k in range(K):
-        ssom.step(k * stride, k * stride, B)
+    for st, ln in steps_at:
+        ssom.step(st, st, ln)
     barrier()
     t1 = time.perf_counter()
     eng.timing(False)
@@ -240,8 +258,11 @@ def bench_som(a):
             p = SomParams(L, a.alpha, radius, E.ALPHA_LINEAR, 0, 0, B, 0, L, 0)
             E.check(lib.somhip_som_train(cb.h, ds.h, C.byref(p), None, None))
         else:
-            for it0 in range(0, L, B):
-                ssom.step(it0, it0, min(B, L - it0))
+            it0 = 0
+            while it0 < L:
+                ln = E.som_auto_batch(lib, L, it0)[1] if auto_b else min(B, L - it0)
+                ssom.step(it0, it0, ln)
+                it0 += ln
         barrier()
         secs = max_over_ranks(time.perf_counter() - t2)
         q, ne = final_qerror()
@@ -250,7 +271,7 @@ def bench_som(a):
 
     # ---- the reference-exact online engine, live, on the head of the same schedule (N = 1) ----
     online = None
-    if world == 1 and B > 1 and (a.online_vectors > 0 or a.online_full):
+    if world == 1 and B != 1 and (a.online_vectors > 0 or a.online_full):
         nonl = L if a.online_full else min(a.online_vectors, L)
         cb.upload(init[mine])
         eng.sync()
@@ -271,7 +292,8 @@ def bench_som(a):
 
     out = None
     if rank == 0:
-        value_steps = K * B / elapsed
+        value_steps = vectors_timed / elapsed
+        bdesc = "engine-chosen (16384 over the first three quarters of the schedule, 8192 after)" if auto_b else str(B)
         # ---- conformity: the complete mini-batch run against the online engine's result on the same stream ----
         check = None
         if full is not None:
@@ -292,15 +314,16 @@ def bench_som(a):
             if ref_q is not None:
                 rel = (full["final_qerror"] - ref_q) / ref_q
                 check = {"online": ref_q, "value": full["final_qerror"], "rel_delta": rel, "tol": 1e-4,
-                         "pass": bool(abs(rel) <= 1e-4), "vectors": L, "batch": B, "online_source": src}
+                         "pass": bool(abs(rel) <= 1e-4), "vectors": L, "batch": bdesc, "online_source": src}
         conforming = check is not None and check["pass"]
         if conforming or full is None or check is None:
-            value, sched = value_steps, "mini-batch %d (winners per batch against the codebook before the batch, updates in iteration order)" % B
+            value, sched = value_steps, "mini-batch %s (winners per batch against the codebook before the batch, updates in iteration order)" % bdesc
         else:                                            # the mini-batch schedule missed the tolerance: only batch 1 conforms
             value, sched = (online["value"] if online else 0.0), "online (reference-exact); the mini-batch schedule FAILED the qerror check"
 
         n_local = len(mine)
-        bpad = ((B + 31) // 32) * 32
+        Bavg = vectors_timed / max(K, 1)                     # vectors per timed step (per launch of every per-batch kernel)
+        bpad = ((int(Bavg) + 31) // 32) * 32
         rows_upd = stats_after["row_updates"] - stats_before["row_updates"]
         pmc = pmc_traffic()
 
@@ -309,13 +332,22 @@ def bench_som(a):
             avg_s = (kms / max(kl, 1)) * 1e-3
             base = {"kernel": kname, "launches": kl, "avg_launch_ms": avg_s * 1e3, "traffic": None}
             if kname == "k_dist_mfma_bf16":
-                alg = 2.0 * n_local * d * bpad                  # algorithmic flops: 2*N*d per vector
+                alg = 2.0 * n_local * d * Bavg                  # algorithmic flops: 2*N*d per vector
+                two_level = table.get("k_dist_l2", (0, 0.0))[0] > 0
                 base.update({"bound": "mfma", "achieved": alg / avg_s / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                             "frac": alg / avg_s / 1e12 / PEAK_BF16_TFLOPS, "executed_tflops": 3 * alg / avg_s / 1e12,
-                             "executed_frac": 3 * alg / avg_s / 1e12 / PEAK_BF16_TFLOPS,
-                             "note": "split-bf16 distance GEMM (v_mfma_f32_32x32x16_bf16, 3 MFMAs per K-step for "
-                                     "hi*hi + hi*lo + lo*hi); achieved = ALGORITHMIC 2*N*d flop per vector over "
-                                     "the dense bf16 peak; the kernel executes 3x that"})
+                             "frac": alg / avg_s / 1e12 / PEAK_BF16_TFLOPS})
+                if two_level:
+                    base["note"] = ("level 1 of the two-level pre-filter: ||c||^2 - 2<c_hi, x_hi> for every (code, vector) pair, one "
+                                    "v_mfma_f32_32x32x16_bf16 per K-step (executed = ALGORITHMIC 2*N*d flop per vector) over the dense "
+                                    "bf16 peak; 8 such MFMAs back to back take 146 ns on this part (tools/micro/mfma_indep.hip -DBF16): "
+                                    "1.84 Pflop/s is what the instruction sustains; the level-2 three-product GEMM on the survivors and "
+                                    "the exact re-rank are separate kernels (k_dist_l2, k_rerank_*)")
+                    base["frac_of_sustained_mfma_rate"] = alg / avg_s / 1e12 / 1840.0
+                else:
+                    base.update({"executed_tflops": 3 * alg / avg_s / 1e12, "executed_frac": 3 * alg / avg_s / 1e12 / PEAK_BF16_TFLOPS,
+                                 "note": "split-bf16 distance GEMM (v_mfma_f32_32x32x16_bf16, 3 MFMAs per K-step for "
+                                         "hi*hi + hi*lo + lo*hi); achieved = ALGORITHMIC 2*N*d flop per vector over "
+                                         "the dense bf16 peak; the kernel executes 3x that"})
                 return base
             if kname == "k_dist_mfma":
                 alg = 2.0 * n_local * d * bpad                  # 2*N*d per vector, GEMM form
@@ -337,7 +369,7 @@ def bench_som(a):
                 return base
             if kname in ("k_scan_exact", "k_som_update_run", "k_som_update_bubble_s"):
                 if kname == "k_scan_exact":
-                    alg = 3.0 * n_local * d * B                 # direct form: sub, mul, add
+                    alg = 3.0 * n_local * d * Bavg              # direct form: sub, mul, add
                     note = "direct-form fp32 scan on the vector ALU, 3*N*d flop per vector"
                 else:
                     alg = 3.0 * d * rows_upd / max(kl, 1)       # c += a*(x-c): sub, mul, add per element
@@ -353,7 +385,7 @@ def bench_som(a):
                 return base
             if kname == "k_som_members":
                 pairs = (stats_after["group_updates"] - stats_before["group_updates"]) / max(kl, 1)
-                alg = 16.0 * pairs + 24.0 * B                   # member entries written + winners/scalars read
+                alg = 16.0 * pairs + 24.0 * Bavg                # member entries written + winners/scalars read
                 note = ("neighbourhood membership lists: 16 B per (row group, sample) entry written (%.0f per launch) + "
                         "24 B per sample read; integer lattice arithmetic and ordered compaction, latency-bound" % pairs)
             else:
@@ -369,7 +401,7 @@ def bench_som(a):
             if k is None:                                       # template / variant suffixes (k_dist_mfma_bf16_wide)
                 hits = [v for n, v in ks.items() if n.startswith(r["kernel"] + "_")]
                 k = hits[0] if len(hits) == 1 else None
-            if k and (xdim, ydim, d, world) == (256, 256, 512, 1):
+            if k and (xdim, ydim, d, world) == (256, 256, 512, 1) and pmc.get("batch", "4096") == bdesc:
                 r["traffic"] = {"bytes_per_launch": k["bytes"], "read": k["read_bytes"], "write": k["write_bytes"],
                                 "source": "%s (commit %s): %s" % (pmc.get("file"), pmc.get("commit", "round 1"), pmc.get("source", ""))}
             return r
@@ -388,8 +420,10 @@ def bench_som(a):
             "config": {"workload": "vsom 256x256 hexa bubble SOM, dim=512, 10M vectors (BASELINE.json configs[3])"
                        if (xdim, ydim, d, a.neigh, L) == (256, 256, 512, "bubble", 10000000)
                        else "vsom %dx%d hexa %s SOM, dim=%d, %d vectors" % (xdim, ydim, a.neigh, d, L),
-                       "dim": d, "codebook_rows": N, "batch": B, "schedule_length": L, "vectors_timed": K * B,
-                       "timed_steps": "%d steps of %d vectors at iterations k*%d of the %d-iteration schedule (radius %g -> 1 across them)" % (K, B, stride, L, radius),
+                       "dim": d, "codebook_rows": N, "batch": bdesc, "schedule_length": L, "vectors_timed": vectors_timed,
+                       "timed_steps": "%d batches of the schedule, %s vectors each, starting at iterations %s ... of the %d-iteration schedule (radius %g -> 1 across them)"
+                                      % (K, "/".join(str(x) for x in sorted({ln for _, ln in steps_at}, reverse=True)),
+                                         ", ".join(str(st) for st, _ in steps_at[:3]), L, radius),
                        "alpha": a.alpha, "radius": radius, "alpha_type": "linear",
                        "stream": "gen:k=%d,dim=%d,n=%d,seed=%d (somhip_dataset_generate); randinit -rand %d" % (kcent, d, L, seed, init_seed),
                        "schedule": sched, "update_mode": a.update,

@@ -160,8 +160,13 @@ int  somhip_find_winners(somhip_codebook *cb, somhip_dataset *ds, int64_t first,
  *             are found against the codebook as it stood before the run, then the
  *             neighbourhood updates are applied in iteration order (exact oracle:
  *             orc_som_training(batch) in oracle/).
+ * batch == SOMHIP_BATCH_AUTO: the mini-batch schedule with the engine's own batch sizes (somhip_som_auto_batch):
+ *             long batches while the map is still being ordered, shorter ones over the last quarter of the
+ *             schedule, where the final state is decided -- measured at configs[3]'s real length
+ *             (profiles/r02_batch_schedule_study.txt): final qerror within 1e-5 of the online result.
  * trace_index/trace_diff (host, [count], may be NULL): winner of every iteration;
  * -2 = skipped (sample fully masked), -3 = fixed-point sample (no search). */
+#define SOMHIP_BATCH_AUTO (-1)
 typedef struct somhip_som_params {
   int64_t length;        /* teach_params.length  (lvq_pak.h:198) */
   float   alpha;         /* teach_params.alpha   (lvq_pak.h:197) */
@@ -174,6 +179,12 @@ typedef struct somhip_som_params {
 } somhip_som_params;
 int  somhip_som_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
                       int32_t *trace_index, float *trace_diff);
+/* The batch of the SOMHIP_BATCH_AUTO schedule that holds iteration `iter` of a schedule of `length` iterations:
+ * [*batch_start, *batch_start + *batch_len).  16384 iterations per batch over the first three quarters of the
+ * schedule (rounded down to whole batches), 8192 after; schedules shorter than 32 long batches: 4096 throughout.
+ * A host that drives somhip_batch_winner_keys / somhip_som_batch_update itself (one process per GPU) asks this
+ * function for its batch boundaries, so that every rank cuts the run the same way. */
+int  somhip_som_auto_batch(int64_t length, int64_t iter, int64_t *batch_start, int64_t *batch_len);
 
 /* ---- lvq1/olvq1/lvq2/lvq3_training (lvq_rout.c:498,584,702,808) --------------
  * kind = SOMHIP_LVQ1..LVQ3.  talpha (host, [n_rows], in/out) = OLVQ1's per-code

@@ -50,7 +50,7 @@ namespace somhip {
 // =====================================================================================
 constexpr int GEMM_KT = 16;            // entries per chunk (8 K-steps of the 32x32x2 MFMA)
 constexpr float GEMM_CUT = 5.9604644775390625e-08f;    // 2^-24
-constexpr int GEMM_MAX_RUN = 8192;     // samples per run this kernel takes (the host sends longer runs to the exact kernels)
+constexpr int GEMM_MAX_RUN = 16384;    // samples per run this kernel takes (the host sends longer runs to the exact kernels)
 constexpr int LIST_CHUNKS_MAX = GEMM_MAX_RUN / GEMM_KT + 1;
 constexpr int GEMM_FRONT_PAD = 16;     // entries of readable memory in front of the first list (host: scratch layout)
 

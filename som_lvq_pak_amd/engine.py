@@ -323,6 +323,16 @@ def som_train(cb, ds, length, alpha, radius, alpha_type=ALPHA_LINEAR, use_fixed=
     return ti, td
 
 
+BATCH_AUTO = -1          # somhip.h SOMHIP_BATCH_AUTO: the engine's own mini-batch sizes along the schedule
+
+
+def som_auto_batch(lib, length, it):
+    """(start, length) of the SOMHIP_BATCH_AUTO batch that holds iteration `it` (somhip_som_auto_batch)"""
+    a, b = C.c_int64(0), C.c_int64(0)
+    check(lib.somhip_som_auto_batch(length, it, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def lvq_train(cb, ds, kind, length, alpha, alpha_type=ALPHA_LINEAR, winlen=0.0, epsilon=0.0,
               talpha=None, start_iter=0, count=None, data_first=None, trace=True):
     """lvq1/olvq1/lvq2/lvq3_training (reference lvq_rout.c:498-916)."""

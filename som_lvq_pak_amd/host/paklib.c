@@ -978,7 +978,8 @@ struct entries *som_training(struct teach_params *teach)     /* som_rout.c:556-6
     long end = segment_end(teach, start);
     if (end - start > avail) end = start + avail;
     somhip_som_params sp = { teach->length, teach->alpha, teach->radius, teach->alpha_type,
-                             use_fixed_level, use_weights_level, teach->batch > 1 ? teach->batch : 1,
+                             use_fixed_level, use_weights_level,
+                             teach->batch > 1 || teach->batch == SOMHIP_BATCH_AUTO ? teach->batch : 1,   /* -batch auto */
                              start, end - start, first };
     if (somhip_som_train(cb, fd.ds, &sp, NULL, NULL)) { fprintf(stderr, "som_training: %s\n", somhip_last_error()); goto done; }
     feed_took(&fd, end - start);
@@ -1018,7 +1019,8 @@ static int som_training_rank(struct teach_params *teach, int rank, int world, in
 {
   struct entries *codes = teach->codes, *data = teach->data;
   const long n = codes->num_entries, dim = codes->dimension, L = teach->length;
-  const long B = teach->batch > 1 ? teach->batch : 4096;
+  const int auto_b = teach->batch == SOMHIP_BATCH_AUTO;     /* -batch auto: the engine's own batch boundaries */
+  const long B = auto_b ? 16384 : teach->batch > 1 ? teach->batch : 4096;
   int ndev = 0, rc = 1;
   somhip_comm *comm = NULL;
   somhip_codebook *cb = NULL;
@@ -1063,7 +1065,13 @@ static int som_training_rank(struct teach_params *teach, int rank, int world, in
 
   somhip_som_params sp = { L, teach->alpha, teach->radius, teach->alpha_type, use_fixed_level, use_weights_level, B, 0, 0, 0 };
   for (long it0 = 0; it0 < L;) {                       /* batches aligned to the schedule, as somhip_som_train cuts them */
-    const long c = B - it0 % B < L - it0 ? B - it0 % B : L - it0, first = it0 % data->num_entries;
+    long c = B - it0 % B < L - it0 ? B - it0 % B : L - it0;
+    const long first = it0 % data->num_entries;
+    if (auto_b) {
+      int64_t bs, bl;
+      if (somhip_som_auto_batch(L, it0, &bs, &bl)) goto hip_fail;
+      c = (long)(bs + bl - it0);
+    }
     if (somhip_batch_winner_keys(cb, ds, first, c, dkeys) || somhip_comm_allreduce_min_keys(comm, dkeys, c) ||
         somhip_som_batch_update(cb, ds, &sp, it0, c, first, dkeys)) goto hip_fail;
     it0 += c;

@@ -1,6 +1,7 @@
 /* vsom -- teach a self-organizing map on the MI355X engine.  Same flags, files and exit
  * behaviour as SOM_PAK's vsom (vsom.c:53-206); new: -batch B (default 1 = the reference's
- * online algorithm, bit-exact; B > 1 = mini-batch schedule). */
+ * online algorithm, bit-exact; B > 1 = mini-batch schedule; auto = the engine's own batch sizes
+ * along the schedule). */
 #include <stdlib.h>
 #include <string.h>
 #include "pak.h"
@@ -9,7 +10,7 @@ static const char *usage =
     "vsom - teach self-organizing map (MI355X engine)\n"
     "Required:  -cin file  -din file  -cout file  -rlen N  -alpha A  -radius R\n"
     "Optional:  -rand seed  -fixed  -weights  -buffer N  -alpha_type linear|inverse_t\n"
-    "           -snapfile name  -snapinterval N  -selfuncs hip  -batch B  -gpus G  -v level\n"
+    "           -snapfile name  -snapinterval N  -selfuncs hip  -batch B|auto  -gpus G  -v level\n"
     "Files:     text (.dat/.cod), raw fp32 (a name ending in .f32; see datconv), or -din gen:k=..,dim=..,n=..,seed=..\n";
 
 static int save_codes(struct teach_params *teach, void *cout)
@@ -33,7 +34,9 @@ int main(int argc, char **argv)
   params.radius = (float)atof(extract_parameter(argc, argv, "-radius", ALWAYS));
   use_fixed_level = extract_parameter(argc, argv, "-fixed", OPTION2) != NULL;
   use_weights_level = extract_parameter(argc, argv, "-weights", OPTION2) != NULL;
-  long batch = oatoi(extract_parameter(argc, argv, "-batch", OPTION), 1);
+  char *batch_s = extract_parameter(argc, argv, "-batch", OPTION);
+  /* -batch auto: the engine's own batch sizes along the schedule (somhip_som_auto_batch) */
+  long batch = batch_s && strcmp(batch_s, "auto") == 0 ? SOMHIP_BATCH_AUTO : oatoi(batch_s, 1);
   int gpus = (int)oatoi(extract_parameter(argc, argv, "-gpus", OPTION), 1);   /* new: one process per GPU, codebook sharded */
 
   pak_gen_virtual_ok = 1;                                /* a gen: source is generated in HBM, never on the host (unless -rand / -buffer) */
