@@ -872,6 +872,98 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1w(CbView cb, int d8
   }
 }
 
+// The same workgroup tile, staging and LDS layout with v_mfma_f32_16x16x32_bf16: a stage of 4 k-blocks is ONE K-step of
+// 32 dims; lane (r = lane & 15, kg = lane >> 4) supplies k-block kg of row / sample r, which is one 16-byte piece of the
+// staged tiles as they are.  A wave's 64 x 128 tile is 4 x 8 MFMAs per stage on the same 12 fragment reads; register v
+// of an output tile is row 4 (lane >> 4) + v, column lane & 15.  (The 16x16x32 form sustains a higher rate than
+// 32x32x16 on this part: MI355X_MICROARCH.md, bare-loop measurements.)
+template <int BD_KB>
+__global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1w16(CbView cb, int d8, const uint4 *__restrict__ chi,
+                                                                 const uint4 *__restrict__ xhi, const float *__restrict__ cn,
+                                                                 int64_t bpad, float *__restrict__ wmin) {
+  static_assert(BD_KB == 4, "one K-step of 32 dims per stage");
+  constexpr int CH = 0, XH = 4 * BD_KB * 64, TOT = XH + 8 * BD_KB * 32;
+  __shared__ uint4 lds[2 * TOT];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;                // this wave multiplies code group wr x sample tiles 4 wc .. 4 wc + 3
+  const int kg = lane >> 4, l15 = lane & 15;
+  const int64_t g0 = static_cast<int64_t>(blockIdx.y) * 4;
+  const int64_t st0 = static_cast<int64_t>(blockIdx.x) * 8;
+  const int64_t nst = bpad / 32;
+  const int arr = wave & 1, sel = wave >> 1;
+  const int64_t gsrc = g0 + sel < cb.ngroups ? g0 + sel : cb.ngroups - 1;
+  const uint4 *pc = chi + (gsrc * d8 + 2 * arr) * 64 + lane;
+  const uint4 *px[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const int64_t ts = st0 + 2 * sel + t < nst ? st0 + 2 * sel + t : nst - 1;
+    px[t] = xhi + (ts * d8 + 2 * arr) * 32 + lane;
+  }
+  const int dc = CH + (sel * BD_KB + 2 * arr) * 64;
+  const int dx = XH + ((2 * sel) * BD_KB + 2 * arr) * 32;             // + t * BD_KB * 32
+  const int nstage = d8 / BD_KB;
+  auto issue = [&](int s) {
+    uint4 *buf = lds + (s & 1) * TOT;
+    const int kb0 = s * BD_KB;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      __builtin_amdgcn_global_load_lds((glb_void *)(pc + (kb0 + k) * 64), (lds_void *)(buf + dc + k * 64), 16, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+      __builtin_amdgcn_global_load_lds((glb_void *)(px[t] + kb0 * 32), (lds_void *)(buf + dx + t * BD_KB * 32), 16, 0, 0);
+  };
+  f32x4v acc[4][8];                                       // [16-row block of the group][16-sample block of the wave's 128]
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[i][j][r] = 0.0f;
+  issue(0);
+  for (int s = 0; s < nstage; s++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < nstage) issue(s + 1);
+    const uint4 *buf = lds + (s & 1) * TOT;
+    bf16x8 ah[4], bh[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) ah[i] = __builtin_bit_cast(bf16x8, buf[CH + (wr * BD_KB + kg) * 64 + 16 * i + l15]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) bh[j] = __builtin_bit_cast(bf16x8, buf[XH + ((wc * 4 + (j >> 1)) * BD_KB + kg) * 32 + 16 * (j & 1) + l15]);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+  }
+  // minimum over the group's 64 rows of ||c||^2 - 2 <c_hi, x_hi> per sample: rows 16 i + 4 kg + v in this lane, the other
+  // three quarters of the rows in lanes l15 + 16, + 32, + 48
+  const int64_t g = g0 + wr;
+  if (g >= cb.ngroups) return;
+  float4 cnv[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) cnv[i] = *reinterpret_cast<const float4 *>(cn + g * 64 + 16 * i + 4 * kg);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int64_t st = st0 + wc * 4 + (j >> 1);
+    float m = 3.4e38f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      m = fminf(m, cnv[i].x - 2.0f * acc[i][j][0]);
+      m = fminf(m, cnv[i].y - 2.0f * acc[i][j][1]);
+      m = fminf(m, cnv[i].z - 2.0f * acc[i][j][2]);
+      m = fminf(m, cnv[i].w - 2.0f * acc[i][j][3]);
+    }
+    m = fminf(m, __shfl_xor(m, 16, WAVE));
+    m = fminf(m, __shfl_xor(m, 32, WAVE));
+    const int64_t b = st * 32 + 16 * (j & 1) + l15;
+    if (kg == 0 && st < nst && b < bpad) wmin[g * bpad + b] = m;
+  }
+}
+
 // survivors of level 1, gathered by row group: list[g][0 .. cnt[g]) = the samples b with wmin1[g][b] <= gmin1[b] + tau1[b].
 // Grid: (32-sample columns, chunks of groups), as the re-rank's select.
 __global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t count, int64_t bpad, int64_t chunk,

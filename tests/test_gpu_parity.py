@@ -376,6 +376,30 @@ def test_top8_two_level_and_by_group_equal_the_plain_paths(eng, E, oracle):
         assert np.array_equal(bits(gd), bits(want_d)), env
 
 
+def test_engine_chosen_batch_schedule_is_the_documented_one(eng, E):
+    """SOMHIP_BATCH_AUTO: 16384-iteration batches over the first three quarters of the schedule (whole batches), 8192 after;
+    short schedules 4096 -- and a run with it equals the same run made in two explicit segments, bit for bit."""
+    lib = eng.lib
+    L = 32 * 16384
+    t1 = (3 * (L // 4)) // 16384 * 16384
+    assert E.som_auto_batch(lib, L, 0) == (0, 16384)
+    assert E.som_auto_batch(lib, L, t1 - 1) == (t1 - 16384, 16384)
+    assert E.som_auto_batch(lib, L, t1) == (t1, 8192)
+    assert E.som_auto_batch(lib, L, L - 1) == (L - 8192, 8192)
+    assert E.som_auto_batch(lib, 10_000_000, 9_999_999) == (7487488 + (9_999_999 - 7487488) // 8192 * 8192, 10_000_000 - (7487488 + (9_999_999 - 7487488) // 8192 * 8192))
+    assert E.som_auto_batch(lib, 100000, 5000) == (4096, 4096)
+    x, _ = synth(31, 4096, 16, k=5, spread=2.0)
+    rs = np.random.RandomState(3)
+    init = (x[rs.randint(0, 4096, 256)] + 0.1 * rs.standard_normal((256, 16))).astype(np.float32)
+    ds = E.Dataset(eng, x)
+    a = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, 16, 16)
+    E.som_train(a, ds, L, 0.05, 8.0, batch=E.BATCH_AUTO, trace=False)
+    b = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, 16, 16)
+    E.som_train(b, ds, L, 0.05, 8.0, batch=16384, count=t1, trace=False)
+    E.som_train(b, ds, L, 0.05, 8.0, batch=8192, start_iter=t1, trace=False)
+    assert np.array_equal(bits(a.download()), bits(b.download()))
+
+
 # --------------------------------------------------------------------------- lvq*_training
 LVQ_CASES = [("lvq1", 1, {}), ("olvq1", 2, {}), ("lvq2", 3, {"winlen": 0.3}),
              ("lvq3", 4, {"winlen": 0.3, "epsilon": 0.1}), ("lvq1_invt", 1, {"alpha_type": 2})]
