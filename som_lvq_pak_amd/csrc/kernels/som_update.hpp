@@ -55,7 +55,8 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
                                                      MemberEntry *__restrict__ ent,
                                                      unsigned long long *__restrict__ stats,
                                                      int64_t xoff_first = -1, int64_t xoff_rows = 0,
-                                                     int xoff_scale = 0) {
+                                                     int xoff_scale = 0, uint32_t tail_need = 0,
+                                                     uint32_t *__restrict__ lstart = nullptr) {
   // xoff_first >= 0 (the consumer is K4s): the entry carries, instead of the sample's index in the run, where its
   // row starts in the data array in float4 units -- ((xoff_first + index) mod xoff_rows) * d / 4 -- so that the
   // update kernel's scalar unit adds instead of wrapping and multiplying per entry
@@ -81,8 +82,20 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
   MemberEntry *out = ent + g * list_stride(count);
   uint32_t base = 0;
   unsigned long long rows_total = 0, pairs_total = 0;
+  // tail_need > 0 (the consumer is K4m, which walks a list from its END and stops once every unit's decay is below its
+  // cut): only the tail of the list is made -- the trips run from the end of the batch, the entries land at the end
+  // of the group's region (lstart[g] says where the list begins), and the walk stops after the trip in which the
+  // tail has collected tail_need entries that hold EVERY live unit (the host sizes tail_need so that K4m stops
+  // inside them, whole chunks included: the result is the one the full list gives, bit for bit).  At radius 128 that
+  // is the last ~500 of a batch's 16 384 samples instead of all of them.
+  __shared__ uint32_t s_full;
+  if (tid == 0) s_full = 0u;
+  const bool tail = tail_need != 0u;
+  uint32_t pos_end = static_cast<uint32_t>(count);
+  const int64_t ntrips = (count + NT * RR - 1) / (NT * RR);
 
-  for (int64_t b0 = 0; b0 < count; b0 += NT * RR) {
+  for (int64_t trip = 0; trip < ntrips; trip++) {
+    const int64_t b0 = tail ? count - (trip + 1) * (NT * RR) : trip * (NT * RR);   // (tail: may start below 0)
     unsigned long long mm[RR];
     float al[RR];
 #pragma unroll
@@ -90,7 +103,7 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
       const int64_t b = b0 + NT * r + tid;
       unsigned long long m = 0;
       float alpha_b = 0.f;
-      if (b < count) {
+      if (b >= 0 && b < count) {
       const StepScalars s = sc[b];
       int2 w;
       if (keys) {                                        // winners decoded here (K4a's rule), no extra launch
@@ -169,11 +182,14 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
     }
     // ordered compaction of the trip: ballots -> (round, wave) counts -> one wavefront scans them
     unsigned long long bal[RR];
+    uint32_t nfull = 0;
 #pragma unroll
     for (int r = 0; r < RR; r++) {
       bal[r] = __ballot(mm[r] != 0);
       if (lane == 0) s_wcount[r * NW + wave] = __popcll(bal[r]);
+      if (tail) nfull += __popcll(__ballot((mm[r] & live_mask) == live_mask));
     }
+    if (tail && lane == 0 && nfull) atomicAdd(&s_full, nfull);
     __syncthreads();
     if (wave == 0) {
       const uint32_t c = lane < RR * NW ? s_wcount[lane] : 0u;
@@ -196,16 +212,20 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
         e.sample = xoff_first < 0 ? static_cast<uint32_t>(bidx)
                                   : static_cast<uint32_t>(((xoff_first + bidx) % xoff_rows) * xoff_scale);   // scale: d/4 (float4 units) or 4 d (bytes)
         e.alpha = al[r]; e.mask = m;
-        out[base + s_wcount[r * NW + wave] + __popcll(bal[r] & ((1ull << lane) - 1))] = e;
+        const uint32_t at = tail ? pos_end - s_wcount[RR * NW] : base;
+        out[at + s_wcount[r * NW + wave] + __popcll(bal[r] & ((1ull << lane) - 1))] = e;
         rows_total += __popcll(m);
         pairs_total += 1;
       }
     }
-    base += s_wcount[RR * NW];
+    if (tail) pos_end -= s_wcount[RR * NW]; else base += s_wcount[RR * NW];
+    const bool enough = tail && s_full >= tail_need;
     __syncthreads();
+    if (enough) break;
   }
-  if (tid == 0) cnt[g] = base;
-  if (tid < LIST_PAD) { MemberEntry z; z.sample = 0u; z.alpha = 0.0f; z.mask = 0ull; out[base + tid] = z; }
+  if (tail) base = static_cast<uint32_t>(count) - pos_end;
+  if (tid == 0) { cnt[g] = base; if (lstart) lstart[g] = tail ? pos_end : 0u; }
+  if (tid < LIST_PAD) { MemberEntry z; z.sample = 0u; z.alpha = 0.0f; z.mask = 0ull; out[(tail ? static_cast<uint32_t>(count) : base) + tid] = z; }
   // instrumentation: (row, iteration) updates and (row group, iteration) pairs of this run
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256, 2) void k_som_update_gemm(CbView cb, const flo
                                                             const uint32_t *__restrict__ cnt,
                                                             const MemberEntry *__restrict__ ent,
                                                             const uint32_t *__restrict__ order,
-                                                            unsigned long long *__restrict__ stats) {
+                                                            unsigned long long *__restrict__ stats,
+                                                            const uint32_t *__restrict__ lstart = nullptr) {
   static_assert(sizeof(MemberEntry) == 16, "four entries per s_load_dwordx16");
   constexpr int DW = 128 * NTW;                         // dims per workgroup
   constexpr int KT = GEMM_KT;
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(256, 2) void k_som_update_gemm(CbView cb, const flo
   const int d0 = static_cast<int>(item % nslices) * DW;  // first dim of the slice
   const int n_ent = __builtin_amdgcn_readfirstlane(static_cast<int>(cnt[g]));
   if (n_ent == 0) return;
-  const MemberEntry *list = ent + g * list_stride(count);
+  // (K4b in tail mode makes only the end of the list, at the end of the group's region: lstart says where it begins)
+  const MemberEntry *list = ent + g * list_stride(count) + (lstart ? __builtin_amdgcn_readfirstlane(static_cast<int>(lstart[g])) : 0);
   const bool live = g * WAVE + lane < cb.n;
 
   f32x16 acc[NTW][2];                                   // [dim tile][unit half]

@@ -1039,8 +1039,10 @@ def test_gemm_update_mode_equals_exact_within_rounding(eng, E, oracle, xd, yd, d
     if length == B:
         want, wi, _ = oracle.som_train(init, xd, yd, 3, 1, x, B, alpha, radius, batch=B)
     got = {}
-    for mode in ("exact", "gemm"):
-        eng.set_update_mode(mode)
+    for mode in ("exact", "gemm", "gemm_full_lists"):
+        eng.set_update_mode(mode.split("_")[0])
+        if mode == "gemm_full_lists":
+            os.environ["SOMHIP_GEMM_FULL_LISTS"] = "1"       # K4b makes every list whole instead of the tail the walk can reach
         try:
             cb = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, xd, yd)
             s0 = eng.scan_stats()
@@ -1050,6 +1052,10 @@ def test_gemm_update_mode_equals_exact_within_rounding(eng, E, oracle, xd, yd, d
             cb.close()
         finally:
             eng.set_update_mode("exact")
+            os.environ.pop("SOMHIP_GEMM_FULL_LISTS", None)
+    # the tail of a list is all the backward walk ever reaches: same bits as with whole lists, same entries walked
+    assert np.array_equal(bits(got["gemm"][0]), bits(got["gemm_full_lists"][0]))
+    assert got["gemm"][2] == got["gemm_full_lists"][2] and got["gemm"][3] <= got["gemm_full_lists"][3]
     if want is None:
         want, wi = got["exact"][0], got["exact"][1]
     assert np.array_equal(got["exact"][1], wi) and np.array_equal(got["gemm"][1], wi)
@@ -1058,7 +1064,38 @@ def test_gemm_update_mode_equals_exact_within_rounding(eng, E, oracle, xd, yd, d
     scale = float(np.abs(want).max())
     assert float(np.abs(got["gemm"][0] - want).max()) <= 8e-6 * scale
     if (xd, yd) == (16, 16):
-        assert got["gemm"][2] < 0.3 * got["gemm"][3]                          # most of every 4096-entry list skipped
+        assert got["gemm"][2] < 0.3 * got["gemm_full_lists"][3]               # most of every 4096-entry list skipped
+    ds.close()
+
+
+def test_gemm_update_makes_only_the_reachable_tail_of_a_list(eng, E):
+    """Update mode gemm on a map with many row groups, a big radius and a long schedule (rate ~ constant inside the batch):
+    K4b makes only the tail of every list that the backward walk can reach before every unit's decay is below the cut --
+    far fewer entries than the whole lists, the same entries walked, the same bits."""
+    xd, yd, d, B = 256, 128, 128, 4096
+    ds = E.Dataset(eng, generate=(21, 16, d, 0, B))
+    lo, hi, cnt = E.column_minmax(ds)
+    init = E.randinit_from_bbox(lo, hi, cnt, xd, yd, 9)
+    got = {}
+    eng.set_update_mode("gemm")
+    try:
+        for mode in ("tail", "full"):
+            if mode == "full":
+                os.environ["SOMHIP_GEMM_FULL_LISTS"] = "1"
+            try:
+                cb = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, xd, yd)
+                s0 = eng.scan_stats()
+                E.som_train(cb, ds, 64 * B, 0.05, 64.0, batch=B, count=B, trace=False)
+                s1 = eng.scan_stats()
+                got[mode] = (cb.download(), s1["gemm_entries"] - s0["gemm_entries"], s1["group_updates"] - s0["group_updates"])
+                cb.close()
+            finally:
+                os.environ.pop("SOMHIP_GEMM_FULL_LISTS", None)
+    finally:
+        eng.set_update_mode("exact")
+    assert np.array_equal(bits(got["tail"][0]), bits(got["full"][0]))
+    assert got["tail"][1] == got["full"][1] > 0
+    assert got["tail"][2] < 0.6 * got["full"][2]
     ds.close()
 
 
