@@ -363,7 +363,10 @@ __global__ __launch_bounds__(256) void k_max_norm(CbView cb, const float *__rest
 // a run of samples -> bf16 hi/lo sample tiles xt[sb][kb][32][8].  grid = (32-sample tiles, slices of the k-blocks)
 __global__ void k_pack_samples_bf16(const float *__restrict__ rows, int64_t n_rows, int d, int d8,
                                     int64_t first, int64_t count, uint4 *__restrict__ xhi,
-                                    uint4 *__restrict__ xlo, unsigned int *__restrict__ zero_word) {
+                                    uint4 *__restrict__ xlo, unsigned int *__restrict__ zero_word,
+                                    uint4 *__restrict__ xrow = nullptr) {
+  // xrow (level 2 of the two-level pre-filter gathers single samples): the same pieces sample by sample,
+  // xrow[(sample * d8 + kb) * 2 + {hi, lo}] -- a sample's operands of consecutive K-steps are then consecutive bytes
   const int64_t sb = blockIdx.x;
   if (zero_word && sb == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_word = 0u;   // max ||c||^2 accumulator of the next kernel
   const int per = (d8 + gridDim.y - 1) / gridDim.y;
@@ -390,6 +393,7 @@ __global__ void k_pack_samples_bf16(const float *__restrict__ rows, int64_t n_ro
     split8(a, b, hi, lo);
     xhi[(sb * d8 + kb) * 32 + sidx] = hi;
     xlo[(sb * d8 + kb) * 32 + sidx] = lo;
+    if (xrow) { xrow[(smp * d8 + kb) * 2] = hi; xrow[(smp * d8 + kb) * 2 + 1] = lo; }
   }
 }
 
@@ -1001,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_dist_l2(CbView cb, int d8, const uint4 
                                                  const float *__restrict__ cn, const float *__restrict__ tau, int64_t bpad,
                                                  const uint32_t *__restrict__ cnt, const uint16_t *__restrict__ list,
                                                  float *__restrict__ wmin, uint64_t *__restrict__ wmask,
-                                                 unsigned long long *__restrict__ stats) {
+                                                 unsigned long long *__restrict__ stats, const uint4 *__restrict__ xrow = nullptr) {
   const int64_t g = blockIdx.x;
   const int n = static_cast<int>(cnt[g]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
@@ -1013,7 +1017,11 @@ __global__ __launch_bounds__(256) void k_dist_l2(CbView cb, int d8, const uint4 
     const bool valid = slot < n;
     const int64_t b = list[g * bpad + (valid ? slot : 0)];
     const uint4 *pa = chi + (g * d8 + half) * 64 + l31, *pl = clo + (g * d8 + half) * 64 + l31;
-    const uint4 *pxh = xhi + ((b >> 5) * d8 + half) * 32 + (b & 31), *pxl = xlo + ((b >> 5) * d8 + half) * 32 + (b & 31);
+    // operand B: this lane's sample, k-block o + half -- from the sample-major copy when there is one (consecutive bytes
+    // per sample: whole cache lines are used), else from the 32-sample tiles (16 bytes out of every 512)
+    const uint4 *pxh = xrow ? xrow + (b * d8 + half) * 2 : xhi + ((b >> 5) * d8 + half) * 32 + (b & 31);
+    const uint4 *pxl = xrow ? pxh + 1 : xlo + ((b >> 5) * d8 + half) * 32 + (b & 31);
+    const int xs = xrow ? 2 : 32;                          // uint4 between consecutive k-blocks of one sample
     f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -1028,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_dist_l2(CbView cb, int d8, const uint4 
       for (int u = 0; u < DEPTH; u++) {
         const int o = 2 * (ks0 + u < nks ? ks0 + u : nks - 1);
         rA0[u] = pa[o * 64]; rA1[u] = pa[o * 64 + 32]; rL0[u] = pl[o * 64]; rL1[u] = pl[o * 64 + 32];
-        rBH[u] = pxh[o * 32]; rBL[u] = pxl[o * 32];
+        rBH[u] = pxh[o * xs]; rBL[u] = pxl[o * xs];
       }
 #pragma unroll
       for (int u = 0; u < DEPTH; u++) {
@@ -1043,6 +1051,112 @@ __global__ __launch_bounds__(256) void k_dist_l2(CbView cb, int d8, const uint4 
           acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, bh, acc[0], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, bh, acc[1], 0, 0, 0);
         }
+      }
+    }
+    // same bit <-> row rule as prefilter_epilogue: register r of block i is row 32 i + (r & 3) + 8 (r >> 2) + 4 half
+    float sv[2][16];
+    float m = 3.4e38f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float v = cn[g * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half] - 2.0f * acc[i][r];
+        sv[i][r] = v;
+        m = fminf(m, v);
+      }
+    m = fminf(m, __shfl_xor(m, 32, WAVE));
+    const float thr = m + tau[b];
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (sv[i][r] <= thr) bits |= 1u << (16 * i + r);
+    const uint32_t other = __shfl_xor(bits, 32, WAVE);
+    if (half == 0 && valid) {
+      wmin[g * bpad + b] = m;
+      wmask[g * bpad + b] = static_cast<uint64_t>(bits) | (static_cast<uint64_t>(other) << 32);
+    }
+  }
+}
+
+// level 2 with the group's tiles resident in LDS (dims up to 512: 64 rows x 512 dims x (hi + lo) = 128 KiB): one workgroup
+// per row group brings its 2 d8 one-KiB pieces in by LDS-DMA once, then its four waves take the group's sample tiles in
+// turn -- operand A from LDS, operand B (each lane the pieces of its own gathered sample) from global memory, two blocks
+// of eight K-steps in flight.  With 16 384-vector batches a group has four or five tiles: the operand-A traffic of
+// k_dist_l2 (each tile re-reading the group's 128 KiB through L2) was most of that kernel's time.  Same products in the
+// same order as k_dist_l2.
+constexpr int L2_WAVES = 8;            // waves of a k_dist_l2_lds workgroup (one workgroup per CU: its LDS holds a group's tiles)
+__global__ __launch_bounds__(64 * L2_WAVES, 1) void k_dist_l2_lds(CbView cb, int d8, const uint4 *__restrict__ chi, const uint4 *__restrict__ clo,
+                                                        const uint4 *__restrict__ xhi, const uint4 *__restrict__ xlo,
+                                                        const float *__restrict__ cn, const float *__restrict__ tau, int64_t bpad,
+                                                        const uint32_t *__restrict__ cnt, const uint16_t *__restrict__ list,
+                                                        float *__restrict__ wmin, uint64_t *__restrict__ wmask,
+                                                        unsigned long long *__restrict__ stats, const uint4 *__restrict__ xrow = nullptr) {
+  extern __shared__ uint4 s_l2a[];                         // [hi | lo][d8][64]
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int64_t g = blockIdx.x;
+  const int n = static_cast<int>(cnt[g]);
+  const int ntiles = (n + 31) >> 5;
+  // a crowded group's tiles are dealt to the gridDim.y workgroups of its row, a wave each; the others leave at once
+  if (static_cast<int>(blockIdx.y) * L2_WAVES >= ntiles) return;
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  if (stats && threadIdx.x == 0 && blockIdx.y == 0) atomicAdd(stats, static_cast<unsigned long long>(n));
+  for (int p = wave; p < 2 * d8; p += L2_WAVES) {
+    const uint4 *src = (p < d8 ? chi + (g * d8 + p) * 64 : clo + (g * d8 + (p - d8)) * 64) + lane;
+    __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(s_l2a + p * 64), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const uint4 *sah = s_l2a, *sal = s_l2a + d8 * 64;
+  const int nks = d8 / 2;                                  // K-step ks uses k-blocks 2 ks + half
+  constexpr int D = 8;
+  for (int tile = blockIdx.y * L2_WAVES + wave; tile < ntiles; tile += L2_WAVES * gridDim.y) {
+    const int slot = tile * 32 + l31;
+    const bool valid = slot < n;
+    const int64_t b = list[g * bpad + (valid ? slot : 0)];
+    const uint4 *pxh = xrow ? xrow + (b * d8 + half) * 2 : xhi + ((b >> 5) * d8 + half) * 32 + (b & 31);   // (see k_dist_l2)
+    const uint4 *pxl = xrow ? pxh + 1 : xlo + ((b >> 5) * d8 + half) * 32 + (b & 31);
+    const int xs = xrow ? 2 : 32;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+    uint4 bh[2][D], bl[2][D];
+    auto fetch = [&](int ks0, int buf) {
+#pragma unroll
+      for (int u = 0; u < D; u++) {
+        const int o = 2 * (ks0 + u < nks ? ks0 + u : nks - 1);
+        bh[buf][u] = pxh[o * xs]; bl[buf][u] = pxl[o * xs];
+      }
+    };
+    auto mult = [&](int ks0, int buf) {
+#pragma unroll
+      for (int u = 0; u < D; u++) {
+        if (ks0 + u < nks) {
+          const int kb = 2 * (ks0 + u) + half;
+          const bf16x8 a0 = __builtin_bit_cast(bf16x8, sah[kb * 64 + l31]), a1 = __builtin_bit_cast(bf16x8, sah[kb * 64 + 32 + l31]);
+          const bf16x8 l0 = __builtin_bit_cast(bf16x8, sal[kb * 64 + l31]), l1 = __builtin_bit_cast(bf16x8, sal[kb * 64 + 32 + l31]);
+          const bf16x8 xh = __builtin_bit_cast(bf16x8, bh[buf][u]), xl = __builtin_bit_cast(bf16x8, bl[buf][u]);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xh, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xh, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xl, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xl, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, xh, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, xh, acc[1], 0, 0, 0);
+        }
+      }
+    };
+    fetch(0, 0);
+    for (int ks0 = 0; ks0 < nks; ks0 += 2 * D) {           // two register blocks in rotation (the loop is unrolled over both)
+      if (ks0 + D < nks) fetch(ks0 + D, 1);
+      mult(ks0, 0);
+      if (ks0 + D < nks) {
+        if (ks0 + 2 * D < nks) fetch(ks0 + 2 * D, 0);
+        mult(ks0 + D, 1);
       }
     }
     // same bit <-> row rule as prefilter_epilogue: register r of block i is row 32 i + (r & 3) + 8 (r >> 2) + 4 half
