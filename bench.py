@@ -364,7 +364,9 @@ def bench_som(a):
                              "note": "neighbourhood update of a batch as c' = P c + W X on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 "
                                      "accumulate): achieved = EXECUTED 2*d*64 flop per walked list entry (%.0f per launch; hits whose weight "
                                      "decayed below 2^-24 are skipped) over the fp32 matrix peak; algorithmic_tflops = the reference's "
-                                     "3*d flop per (row, iteration) update (%.0f per launch) at this kernel's time"
+                                     "3*d flop per (row, iteration) update of the list entries K4b made (%.0f per launch: only the tails of "
+                                     "the lists that the walk can reach are made, so most of the reference's updates are not even counted) "
+                                     "at this kernel's time"
                                      % (walked, rows_upd / max(kl, 1))})
                 return base
             if kname in ("k_scan_exact", "k_som_update_run", "k_som_update_bubble_s"):
