@@ -65,7 +65,7 @@ struct RerankInit {
 };
 __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int d, int64_t first,
                              int64_t count, const unsigned int *__restrict__ cn_max_bits,
-                             double err_coeff, float *__restrict__ tau, RerankInit init,
+                             double err_prod, double err_sq, float *__restrict__ tau, RerankInit init,
                              double l1_prod = 0.0, double l1_sq = 0.0, float *__restrict__ tau1 = nullptr) {
   const int64_t b = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -88,19 +88,23 @@ __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, WAVE);
   if (lane == 0) {
-    // err_coeff = the host's bound on |s~ + ||x||^2 - d| / (||x|| + ||c||)^2 for the GEMM in use
+    // |s~ + ||x||^2 - d| <= err_prod ||x|| ||c|| + err_sq (||x|| + ||c||)^2 =: delta3 for the GEMM in use (host:
+    // prefilter_err3); tau = 2 delta3
     const double u = 5.9604644775390625e-08;                         // 2^-24
     const double cmax = sqrt(static_cast<double>(__uint_as_float(*cn_max_bits)) * (1.0 + 4.0 * d * u));
-    const double s = sqrt(acc) + cmax;
-    const double t = 2.0 * err_coeff * s * s * 1.001;
+    const double a = sqrt(acc), s = a + cmax;
+    const double t = 2.0 * (err_prod * a * cmax + err_sq * s * s) * 1.001;
     float tf = static_cast<float>(t);
     if (static_cast<double>(tf) < t) tf = __uint_as_float(__float_as_uint(tf) + 1);   // round up
     tau[b] = tf;
     if (tau1) {                                          // the level-1 (one-product) window of the two-level pre-filter:
-      // |s~1 - s| <= l1_prod ||x|| ||c|| + l1_sq (||x|| + ||c||)^2 =: delta1 (host: prefilter_err_l1), window = 2 delta1.
-      // The product term carries the dropped lo parts; keeping it a PRODUCT matters while the map is still bunched
-      // around the data's mean (||c|| a third of ||x||): (||x|| + ||c||)^2 / 4 would be 1.4x the product there.
-      const double t1 = 2.0 * (l1_prod * sqrt(acc) * cmax + l1_sq * s * s) * 1.001;
+      // |s~1 - s| <= l1_prod ||x|| ||c|| + l1_sq (||x|| + ||c||)^2 =: delta1 (host: prefilter_err_l1).  The window W above
+      // the smallest level-1 group minimum has to (i) hold the exact winner's group: W >= 2 delta1, and (ii) leave
+      // every group outside it with a level-1 minimum beyond what the re-rank looks at, min3 + tau <= s_min + 3 delta3,
+      // i.e. W >= delta1 + 3 delta3 (a group outside has wmin1 > min1 + W >= s_min - delta1 + W).  delta1 >= 3 delta3 in
+      // every ordinary case (the dropped lo parts dwarf the accumulation error), but not for a codebook of tiny norm.
+      const double d1 = (l1_prod * a * cmax + l1_sq * s * s) * 1.001, d3 = 0.5 * static_cast<double>(tf);
+      const double t1 = d1 + (d1 > 3.0 * d3 ? d1 : 3.0 * d3);
       float t1f = static_cast<float>(t1);
       if (static_cast<double>(t1f) < t1) t1f = __uint_as_float(__float_as_uint(t1f) + 1);
       tau1[b] = t1f;
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void k_dist_mfma(CbView cb, const float4 *_
 //     <c, x>  ~  <c_hi, x_hi> + <c_hi, x_lo> + <c_lo, x_hi>          (3 MFMAs per K-step)
 // Products of two bf16 are exact in fp32; what is lost is the dropped lo*lo / r terms
 // (<= 3.1 * 2^-16 ||x|| ||c||) and the fp32 accumulation of 3d terms, both added to the
-// error coefficient tau is built from (somhip.hip prefilter_err_coeff), so the exact
+// error coefficients tau is built from (host_scan.inc prefilter_err3), so the exact
 // re-rank downstream still returns the reference's bits.  Codes and samples are kept as
 // bf16 tiles [group|tile][kb = dim/8][row][8] (16 B per row and k-block = one MFMA operand).
 // =====================================================================================
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(256, 2) void k_dist_mfma_bf16_wide(CbView cb, int d
 // K2c: TWO-LEVEL pre-filter (round 2).  Level 1 is the same GEMM with ONE bf16 product per K-step, hi x hi: a third of
 // the matrix work and half the operand bytes.  Dropping both lo terms costs |<c,x> - <c_hi,x_hi>| <= 2^-8 (1 + 2^-8)
 // ||c|| ||x||, so s~1 is within delta1 ~ 2^-7 ||c|| ||x|| of s and the group of the exact winner has
-// wmin1 <= min wmin1 + tau1, tau1 = 2 delta1 (host: prefilter_err_coeff_l1).  Over a whole configs[3] run that keeps
+// wmin1 <= min wmin1 + tau1, tau1 = delta1 + max(delta1, 3 delta3) (k_sample_tau; host: prefilter_err_l1, prefilter_err3).  Over a whole configs[3] run that keeps
 // 2 ... 17 of the 1024 row groups per sample (tools/survivor_study.py).  Level 2 (k_dist_l2) runs the three-product
 // GEMM on exactly those (group, sample) pairs -- gathered by group, the samples' bf16 pieces loaded per lane -- and
 // writes the wmin / wmask the exact re-rank already consumes.  Entries of wmin that level 2 did not touch keep their

@@ -648,6 +648,30 @@ def test_prefilter_error_is_inside_its_bound(eng, E, mode, d, offset, scale):
     assert ratio.max() < 0.5, ratio.max()            # inside the bound with a factor 2 to spare
 
 
+@pytest.mark.parametrize("cscale", [1e-3, 1e-6, 0.0])
+def test_two_level_prefilter_with_a_codebook_of_tiny_norm(eng, E, oracle, cscale):
+    """||c|| << ||x|| (a map initialised near the origin): the level-1 error bound shrinks with ||c|| while the
+    three-product bound does not, so the level-1 window has to be widened to delta1 + 3 delta3 for the groups left out
+    of level 2 to stay beyond the re-rank's reach.  Winners through the two-level pre-filter = the direct scan's."""
+    rs = np.random.RandomState(17)
+    n, d, m = 4096, 64, 512
+    codes = (cscale * rs.standard_normal((n, d))).astype(np.float32)
+    x = rs.standard_normal((m, d)).astype(np.float32)
+    ini = codes.copy()
+    want_i, want_d, _ = oracle.winners(ini, x)
+    cb, ds = E.Codebook(eng, ini, E.TOPOL_HEXA, E.NEIGH_BUBBLE, 64, 64), E.Dataset(eng, x)
+    got = {}
+    for mode in ("direct", "mfma_bf16"):
+        eng.set_scan_mode(mode)
+        try:
+            keys = E.batch_winner_keys(cb, ds, 0, m) if hasattr(E, "batch_winner_keys") else None
+            ti, td = E.som_train(cb, ds, 64 * m, 0.0, 1.0, batch=m, count=m)     # alpha 0: the search of one batch, no change
+        finally:
+            eng.set_scan_mode("mfma_bf16")
+        assert np.array_equal(ti, want_i[:, 0]), mode
+        assert np.array_equal(bits(td), bits(want_d[:, 0])), mode
+
+
 # --------------------------------------------------------------------------- 8x8-patch row order
 @pytest.mark.parametrize("topol,neigh", [(3, 1), (3, 2), (4, 1), (4, 2)])
 @pytest.mark.parametrize("batch", [1, 48])
