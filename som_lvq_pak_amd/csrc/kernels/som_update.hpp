@@ -56,7 +56,10 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
                                                      unsigned long long *__restrict__ stats,
                                                      int64_t xoff_first = -1, int64_t xoff_rows = 0,
                                                      int xoff_scale = 0, uint32_t tail_need = 0,
-                                                     uint32_t *__restrict__ lstart = nullptr) {
+                                                     uint32_t *__restrict__ lstart = nullptr, int gauss_gemm = 0) {
+  // gauss_gemm (GAUSS only; the consumer is K4m's gaussian form): the entry's mask field carries the winner's lattice
+  // coordinates (x | y << 16) and, in its upper word, the float log2(e) / (2 radius^2) of the iteration; samples whose
+  // rate would be below 2^-40 of alpha for every unit of the group are left out
   // xoff_first >= 0 (the consumer is K4s): the entry carries, instead of the sample's index in the run, where its
   // row starts in the data array in float4 units -- ((xoff_first + index) mod xoff_rows) * d / 4 -- so that the
   // update kernel's scalar unit adds instead of wrapping and multiplying per entry
@@ -121,7 +124,21 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
       // reach (rows) >= radius/0.866 + 1 also bounds the x extent (unit spacing 1, half-unit shifts)
       if (w.x >= 0 && w.y + s.reach >= g_ty0 && w.y - s.reach <= g_ty1 &&
           (GAUSS || (w.x + s.reach >= g_txa && w.x - s.reach <= g_tx1))) {
-        if (GAUSS) m = live_mask;
+        if (GAUSS && gauss_gemm) {
+          // nearest the winner can be to a unit of this group's 8 x 8 patch (or row run), conservatively: half a unit of
+          // hexagonal shift taken off the x distance
+          const int ddx = w.x < g_txa ? g_txa - w.x : (w.x > g_tx1 ? w.x - g_tx1 : 0);
+          const int ddy = w.y < g_ty0 ? g_ty0 - w.y : (w.y > g_ty1 ? w.y - g_ty1 : 0);
+          const double fx = ddx > 0 ? ddx - 0.5 : 0.0;
+          const double lat_min = fx * fx + 0.75 * static_cast<double>(ddy) * ddy;
+          const double coef = 1.4426950408889634 / (2.0 * static_cast<double>(s.thresh) * static_cast<double>(s.thresh));
+          if (lat_min * coef <= 40.0) {
+            const float cf = static_cast<float>(coef);
+            m = (static_cast<unsigned long long>(__float_as_uint(cf)) << 32) |
+                (static_cast<unsigned long long>(static_cast<uint32_t>(w.y) & 0xFFFFu) << 16) | (static_cast<uint32_t>(w.x) & 0xFFFFu);
+            if (m == 0ull) m = 1ull << 63;               // (cannot happen: coef > 0)
+          }
+        } else if (GAUSS) m = live_mask;
         else if (cb.patch_w && small_map) {
           // 8x8 patch, exact integer form: with every lattice quantity a multiple of 1/4,
           //   lattice_sq <= thresh  <=>  (2dx)^2 + 3 dy^2 <= floor(4 thresh)   (hexa)
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
         e.alpha = al[r]; e.mask = m;
         const uint32_t at = tail ? pos_end - s_wcount[RR * NW] : base;
         out[at + s_wcount[r * NW + wave] + __popcll(bal[r] & ((1ull << lane) - 1))] = e;
-        rows_total += __popcll(m);
+        rows_total += (GAUSS && gauss_gemm) ? nlive : __popcll(m);
         pairs_total += 1;
       }
     }

@@ -79,7 +79,13 @@ __device__ __forceinline__ void gemm_dma_piece(const float4 *src, const float *l
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
 }  // (m0 is a reserved register: the compiler keeps nothing in it across statements and cannot be told about the write)
 
-template <int NTW>                     // 32-dim tiles per wave: the workgroup covers 128 * NTW dims
+// GAUSS: gaussian neighbourhoods (gaussian_adapt som_rout.c:511-549) in the same form.  Every sample updates every
+// unit with its own rate a = alpha exp(-lattice_sq / (2 radius^2)), so W is dense: the chain computes the rate per
+// (unit, entry) -- lattice_sq from the lane's unit and the entry's winner (fp32, exact for maps up to 1024 x 1024),
+// v_exp_f32 with the iteration's log2(e) / (2 radius^2) from the entry -- and there is no early stop (a unit far from
+// every winner keeps P = 1): the whole list is walked, 2 * 64 * d flop per entry instead of the 3 * 64 * d of the exact
+// kernels' vector arithmetic.  K4b leaves out the samples whose rate is below 2^-40 alpha for the whole group.
+template <int NTW, bool GAUSS = false> // 32-dim tiles per wave: the workgroup covers 128 * NTW dims
 __global__ __launch_bounds__(256, 2) void k_som_update_gemm(CbView cb, const float *__restrict__ rows, int64_t n_rows,
                                                             int64_t data_first, int64_t count,
                                                             const uint32_t *__restrict__ cnt,
@@ -156,14 +162,25 @@ __global__ __launch_bounds__(256, 2) void k_som_update_gemm(CbView cb, const flo
   // the weights of K-step s of a chunk (entries 2s + 1, then 2s: the walk goes backwards) as the two B operands:
   // b0 = units 0-31 (lanes 0-31: entry 2s, lanes 32-63: entry 2s + 1), b1 = units 32-63 likewise.  q = the quarter
   // that holds the two entries, i0 = the list index of its first entry.
+  int u_tx = 0, u_ty = 0;                                // GAUSS: this lane's unit on the lattice
+  if (GAUSS) txty_of_row(cb, g * WAVE + lane, u_tx, u_ty);
   auto weight_pair = [&](const u32x16_t &q, int i0, int s, float &Pr, float &b0, float &b1) {
     float w[2];
 #pragma unroll
     for (int k = 1; k >= 0; k--) {
       const int i = (2 * s + k) & 3;
-      const unsigned long long mask = i0 + i >= 0 ? (static_cast<unsigned long long>(q[4 * i + 3]) << 32) | q[4 * i + 2] : 0ull;
-      const float ap = __uint_as_float(q[4 * i + 1]) * Pr;
-      w[k] = __builtin_amdgcn_inverse_ballot_w64(mask) ? ap : 0.0f;
+      if (GAUSS) {
+        const uint32_t xy = q[4 * i + 2];
+        const float lat = lattice_sq_small(cb.topol, static_cast<int>(xy & 0xFFFFu), static_cast<int>(xy >> 16), u_tx, u_ty);
+        // (below the start of the list the fields are whatever memory holds: the rate is SELECTED to 0, not multiplied)
+        const float r = __uint_as_float(q[4 * i + 1]) * __builtin_amdgcn_exp2f(-lat * __uint_as_float(q[4 * i + 3]));
+        const float a = (i0 + i >= 0 && live) ? r : 0.0f;
+        w[k] = a * Pr;
+      } else {
+        const unsigned long long mask = i0 + i >= 0 ? (static_cast<unsigned long long>(q[4 * i + 3]) << 32) | q[4 * i + 2] : 0ull;
+        const float ap = __uint_as_float(q[4 * i + 1]) * Pr;
+        w[k] = __builtin_amdgcn_inverse_ballot_w64(mask) ? ap : 0.0f;
+      }
       Pr = Pr - w[k];
     }
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[0]), __float_as_uint(w[1]), false, false);
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_som_update_gemm(CbView cb, const flo
   };
 
   // s_earlier[c] = OR of the masks of every entry before chunk c (chunks c + 1, c + 2, ...): lane = chunk, then a suffix scan
-  if (wave == 0) {
+  if (wave == 0 && !GAUSS) {
     const int nch = (n_ent + KT - 1) / KT;
     unsigned long long carry = 0ull;                     // OR of all chunks beyond the ones handled so far
     for (int c0 = ((nch - 1) / WAVE) * WAVE; c0 >= 0; c0 -= WAVE) {   // blocks of 64 chunks, from the far end of the walk
@@ -193,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_som_update_gemm(CbView cb, const flo
   }
   auto more_after = [&](int c, float Pr) {               // is chunk c + 1 needed, P being the decay after chunk c
     // go on while some live unit both has weight left to give (P >= 2^-24) and an earlier hit to give it to
+    if (GAUSS) return n_ent - (c + 1) * KT > 0;          // dense weights: the whole list
     return n_ent - (c + 1) * KT > 0 && __any(live && Pr >= GEMM_CUT && ((s_earlier[c] >> lane) & 1ull));
   };
 

@@ -1123,6 +1123,36 @@ def test_gemm_update_makes_only_the_reachable_tail_of_a_list(eng, E):
     ds.close()
 
 
+@pytest.mark.parametrize("xd,yd,d,B,radius,alpha,topol", [(32, 24, 128, 1024, 6.0, 0.05, 3), (40, 16, 256, 600, 2.5, 0.03, 4),
+                                                           (16, 16, 512, 2048, 12.0, 0.05, 3)])
+def test_gemm_update_mode_gaussian(eng, E, oracle, xd, yd, d, B, radius, alpha, topol):
+    """gaussian neighbourhoods in update mode gemm: every unit's rate alpha exp(-lattice_sq / (2 radius^2)) per sample as a dense
+    weight matrix on the fp32 matrix pipe, against the exact kernels (= the batch oracle, bit for bit): same winners, the
+    codebook within fp32 rounding of a sum of B products (the rates themselves go through v_exp_f32 instead of a double exp)."""
+    ds = E.Dataset(eng, generate=(13, 12, d, 0, B))
+    lo, hi, cnt = E.column_minmax(ds)
+    init = E.randinit_from_bbox(lo, hi, cnt, xd, yd, 3)
+    x = ds.rows(0, B)
+    want, wi, _ = oracle.som_train(init, xd, yd, topol, 2, x, 8 * B, alpha, radius, batch=B) if False else (None, None, None)
+    got = {}
+    for mode in ("exact", "gemm"):
+        eng.set_update_mode(mode)
+        try:
+            cb = E.Codebook(eng, init, topol, E.NEIGH_GAUSSIAN, xd, yd)
+            s0 = eng.scan_stats()
+            ti, _ = E.som_train(cb, ds, 8 * B, alpha, radius, batch=B, count=B)
+            s1 = eng.scan_stats()
+            got[mode] = (cb.download(), ti, s1["gemm_entries"] - s0["gemm_entries"])
+            cb.close()
+        finally:
+            eng.set_update_mode("exact")
+    assert np.array_equal(got["exact"][1], got["gemm"][1])
+    assert got["exact"][2] == 0 and got["gemm"][2] > 0                       # the matrix-pipe kernel really ran
+    scale = float(np.abs(got["exact"][0]).max())
+    assert float(np.abs(got["gemm"][0] - got["exact"][0]).max()) <= 2e-5 * scale
+    ds.close()
+
+
 def test_gemm_update_mode_falls_back_and_shards_identically(eng, E, oracle):
     """gemm mode is taken only where it applies (bubble, no masks, dim % 128 == 0): a dim-48 map, a gaussian map and
     masked data must give the exact kernels' bits; interleaved shards in gemm mode give the unsharded gemm bits."""
