@@ -71,8 +71,10 @@ int  somhip_engine_set_scan_mode(somhip_engine *e, int mode);
  *                        bit-identical to orc_som_training(batch) in oracle/ -- the default
  *   SOMHIP_UPDATE_GEMM   the same affine map of every unit, c' = P c + sum_j w_j x_j, evaluated as a matrix product
  *                        on the fp32 matrix pipe (kernels/som_update_gemm.hpp); same result up to fp32 rounding of a
- *                        sum instead of a chain, hits whose weight has decayed below 2^-24 skipped; bubble
- *                        neighbourhoods, no masked components, dim a multiple of 128 (otherwise the exact kernels run)
+ *                        sum instead of a chain, hits whose weight has decayed below 2^-24 skipped; no masked
+ *                        components, dim a multiple of 128; gaussian neighbourhoods (maps up to 1024 x 1024): every
+ *                        unit's rate per sample as a dense weight matrix, the rates through the fp32 exp
+ *                        (otherwise the exact kernels run)
  * batch == 1 (the reference's online algorithm) is not affected.  Environment: SOMHIP_UPDATE_MODE=gemm|exact. */
 enum { SOMHIP_UPDATE_EXACT = 0, SOMHIP_UPDATE_GEMM = 1 };
 int  somhip_engine_set_update_mode(somhip_engine *e, int mode);
