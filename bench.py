@@ -9,7 +9,7 @@ alpha 0.05 linear, radius 128 -> 1, over 10 000 000 vectors of the seeded Gaussi
 
 A "step" is one mini-batch through the whole hot path: exact best-matching-unit search for every vector of the
 batch + the in-order neighbourhood update.  Batch sizes are the engine's own schedule (somhip.h SOMHIP_BATCH_AUTO,
-somhip_som_auto_batch: 16384 vectors over the first three quarters of the run, 8192 after; `--batch B` fixes one
+somhip_som_auto_batch: 32768 vectors over the first three quarters of the run, 8192 after; `--batch B` fixes one
 size).  The timed region is EXACTLY --steps such batches of the real 10 M-iteration schedule, evenly spread over
 it (step k = the batch that holds iteration k * length / steps), so the radius sweeps its whole range inside the
 timed region and every step costs what it costs at that point of the real run; `value` = vectors of those batches
@@ -60,7 +60,7 @@ def parse():
                     help="c4 = BASELINE configs[3] (SOM 256x256x512, the headline); c3 = configs[2] (OLVQ1 10k x 256); "
                          "c5 = configs[4] shape (LVQ3 100k x 1024)")
     ap.add_argument("--batch", type=int, default=-1,
-                    help="vectors per mini-batch; -1 (default) = the engine's own schedule (SOMHIP_BATCH_AUTO: 16384 over the first "
+                    help="vectors per mini-batch; -1 (default) = the engine's own schedule (SOMHIP_BATCH_AUTO: 32768 over the first "
                          "three quarters of the run, 8192 after)")
     ap.add_argument("--xdim", type=int, default=256)
     ap.add_argument("--ydim", type=int, default=256)
@@ -184,7 +184,7 @@ def bench_som(a):
         layout = "contiguous row blocks /%d" % world
     lib = eng.lib
     gshard = sharded.GpuShard(eng, cb, ds, lambda: SomParams(L, a.alpha, radius, E.ALPHA_LINEAR, 0, 0, B, 0, 0, 0),
-                              max(B, 16384))
+                              max(B, 32768))
     ssom = sharded.ShardedSom(gshard, B, L)
     # the timed steps: K batches of the schedule, evenly spread over it -- (first iteration, vectors) each
     if auto_b:
@@ -293,7 +293,7 @@ def bench_som(a):
     out = None
     if rank == 0:
         value_steps = vectors_timed / elapsed
-        bdesc = "engine-chosen (16384 over the first three quarters of the schedule, 8192 after)" if auto_b else str(B)
+        bdesc = "engine-chosen (32768 over the first three quarters of the schedule, 8192 after)" if auto_b else str(B)
         # ---- conformity: the complete mini-batch run against the online engine's result on the same stream ----
         check = None
         if full is not None:

@@ -182,7 +182,7 @@ typedef struct somhip_som_params {
 int  somhip_som_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
                       int32_t *trace_index, float *trace_diff);
 /* The batch of the SOMHIP_BATCH_AUTO schedule that holds iteration `iter` of a schedule of `length` iterations:
- * [*batch_start, *batch_start + *batch_len).  16384 iterations per batch over the first three quarters of the
+ * [*batch_start, *batch_start + *batch_len).  32768 iterations per batch over the first three quarters of the
  * schedule (rounded down to whole batches), 8192 after; schedules shorter than 32 long batches: 4096 throughout.
  * A host that drives somhip_batch_winner_keys / somhip_som_batch_update itself (one process per GPU) asks this
  * function for its batch boundaries, so that every rank cuts the run the same way. */

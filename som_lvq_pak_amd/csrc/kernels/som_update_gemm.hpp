@@ -50,8 +50,7 @@ namespace somhip {
 // =====================================================================================
 constexpr int GEMM_KT = 16;            // entries per chunk (8 K-steps of the 32x32x2 MFMA)
 constexpr float GEMM_CUT = 5.9604644775390625e-08f;    // 2^-24
-constexpr int GEMM_MAX_RUN = 16384;    // samples per run this kernel takes (the host sends longer runs to the exact kernels)
-constexpr int LIST_CHUNKS_MAX = GEMM_MAX_RUN / GEMM_KT + 1;
+constexpr int GEMM_MAX_RUN = 65504;    // samples per run this kernel takes (the host sends longer runs to the exact kernels)
 constexpr int GEMM_FRONT_PAD = 16;     // entries of readable memory in front of the first list (host: scratch layout)
 
 template <int NTW> struct GemmA;                         // NTW consecutive floats of a staged row
@@ -98,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void k_som_update_gemm(CbView cb, const flo
   constexpr int KT = GEMM_KT;
   typedef typename GemmA<NTW>::T AT;
   __shared__ __attribute__((aligned(16))) float s_x[2 * KT * DW];              // sample rows of two chunks, [KT][DW] each
-  __shared__ unsigned long long s_earlier[LIST_CHUNKS_MAX + 1];   // units that still have a hit in a chunk before chunk c
+  __shared__ int s_hc[WAVE];                                       // per unit: the furthest chunk (from the list's end) with a hit
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -188,30 +187,29 @@ __global__ __launch_bounds__(256, 2) void k_som_update_gemm(CbView cb, const flo
     b1 = __uint_as_float(r[1]);
   };
 
-  // s_earlier[c] = OR of the masks of every entry before chunk c (chunks c + 1, c + 2, ...): lane = chunk, then a suffix scan
+  // s_hc[u] = the chunk furthest from the list's end that still holds a hit of unit u (-1: none): unit u has an EARLIER
+  // hit than chunk c iff s_hc[u] > c.  Blocks of 64 chunks from the far end of the walk (lane = chunk: the OR of its 16
+  // masks), a ballot per unit; over as soon as every live unit has been seen (at a big radius: the first block).
   if (wave == 0 && !GAUSS) {
     const int nch = (n_ent + KT - 1) / KT;
-    unsigned long long carry = 0ull;                     // OR of all chunks beyond the ones handled so far
-    for (int c0 = ((nch - 1) / WAVE) * WAVE; c0 >= 0; c0 -= WAVE) {   // blocks of 64 chunks, from the far end of the walk
+    int hc = -1;
+    for (int c0 = ((nch - 1) / WAVE) * WAVE; c0 >= 0; c0 -= WAVE) {
       const int c = c0 + lane;
       unsigned long long m = 0ull;
       if (c < nch)
         for (int e = 0; e < KT; e++) { const int idx = n_ent - (c + 1) * KT + e; if (idx >= 0) m |= list[idx].mask; }
-      unsigned long long inc = m;                        // inclusive suffix OR inside the block: lanes above
-#pragma unroll
-      for (int off = 1; off < WAVE; off <<= 1) {
-        const unsigned long long o = __shfl_down(inc, off, WAVE);
-        if (lane + off < WAVE) inc |= o;
+      for (int u = 0; u < WAVE; u++) {
+        const unsigned long long bal = __ballot((m >> u) & 1ull);
+        if (lane == u && hc < 0 && bal) hc = c0 + 63 - __clzll(bal);
       }
-      const unsigned long long above = __shfl_down(inc, 1, WAVE);
-      if (c < nch) s_earlier[c] = (lane + 1 < WAVE ? above : 0ull) | carry;
-      carry |= __shfl(inc, 0, WAVE);
+      if (__all(!live || hc >= 0)) break;
     }
+    s_hc[lane] = hc;
   }
   auto more_after = [&](int c, float Pr) {               // is chunk c + 1 needed, P being the decay after chunk c
     // go on while some live unit both has weight left to give (P >= 2^-24) and an earlier hit to give it to
     if (GAUSS) return n_ent - (c + 1) * KT > 0;          // dense weights: the whole list
-    return n_ent - (c + 1) * KT > 0 && __any(live && Pr >= GEMM_CUT && ((s_earlier[c] >> lane) & 1ull));
+    return n_ent - (c + 1) * KT > 0 && __any(live && Pr >= GEMM_CUT && s_hc[lane] > c);
   };
 
   float P = 1.0f;                                        // lane = unit: decay of everything processed so far
@@ -229,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void k_som_update_gemm(CbView cb, const flo
     weight_pair(q, first_of(0, j), 2 * j + 1, P, b0[2 * j + 1], b1[2 * j + 1]);
     weight_pair(q, first_of(0, j), 2 * j, P, b0[2 * j], b1[2 * j]);
   }
-  __syncthreads();                                       // s_earlier
+  __syncthreads();                                       // s_hc
   bool more = more_after(0, P);
   for (int c = 0;; c++) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of chunk c; the offsets of chunk c + 1

@@ -1020,7 +1020,7 @@ static int som_training_rank(struct teach_params *teach, int rank, int world, in
   struct entries *codes = teach->codes, *data = teach->data;
   const long n = codes->num_entries, dim = codes->dimension, L = teach->length;
   const int auto_b = teach->batch == SOMHIP_BATCH_AUTO;     /* -batch auto: the engine's own batch boundaries */
-  const long B = auto_b ? 16384 : teach->batch > 1 ? teach->batch : 4096;
+  const long B = auto_b ? 32768 : teach->batch > 1 ? teach->batch : 4096;
   int ndev = 0, rc = 1;
   somhip_comm *comm = NULL;
   somhip_codebook *cb = NULL;

@@ -377,16 +377,19 @@ def test_top8_two_level_and_by_group_equal_the_plain_paths(eng, E, oracle):
 
 
 def test_engine_chosen_batch_schedule_is_the_documented_one(eng, E):
-    """SOMHIP_BATCH_AUTO: 16384-iteration batches over the first three quarters of the schedule (whole batches), 8192 after;
+    """SOMHIP_BATCH_AUTO: 32768-iteration batches over the first three quarters of the schedule (whole batches), 8192 after;
     short schedules 4096 -- and a run with it equals the same run made in two explicit segments, bit for bit."""
     lib = eng.lib
-    L = 32 * 16384
-    t1 = (3 * (L // 4)) // 16384 * 16384
-    assert E.som_auto_batch(lib, L, 0) == (0, 16384)
-    assert E.som_auto_batch(lib, L, t1 - 1) == (t1 - 16384, 16384)
+    BL = 32768
+    L = 32 * BL
+    t1 = (3 * (L // 4)) // BL * BL
+    assert E.som_auto_batch(lib, L, 0) == (0, BL)
+    assert E.som_auto_batch(lib, L, t1 - 1) == (t1 - BL, BL)
     assert E.som_auto_batch(lib, L, t1) == (t1, 8192)
     assert E.som_auto_batch(lib, L, L - 1) == (L - 8192, 8192)
-    assert E.som_auto_batch(lib, 10_000_000, 9_999_999) == (7487488 + (9_999_999 - 7487488) // 8192 * 8192, 10_000_000 - (7487488 + (9_999_999 - 7487488) // 8192 * 8192))
+    t10 = (3 * (10_000_000 // 4)) // BL * BL
+    last = t10 + (9_999_999 - t10) // 8192 * 8192
+    assert E.som_auto_batch(lib, 10_000_000, 9_999_999) == (last, 10_000_000 - last)
     assert E.som_auto_batch(lib, 100000, 5000) == (4096, 4096)
     x, _ = synth(31, 4096, 16, k=5, spread=2.0)
     rs = np.random.RandomState(3)
@@ -395,7 +398,7 @@ def test_engine_chosen_batch_schedule_is_the_documented_one(eng, E):
     a = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, 16, 16)
     E.som_train(a, ds, L, 0.05, 8.0, batch=E.BATCH_AUTO, trace=False)
     b = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, 16, 16)
-    E.som_train(b, ds, L, 0.05, 8.0, batch=16384, count=t1, trace=False)
+    E.som_train(b, ds, L, 0.05, 8.0, batch=BL, count=t1, trace=False)
     E.som_train(b, ds, L, 0.05, 8.0, batch=8192, start_iter=t1, trace=False)
     assert np.array_equal(bits(a.download()), bits(b.download()))
 

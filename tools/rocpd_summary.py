@@ -52,9 +52,9 @@ def main():
     f = counters(f"{src}/pmc_FETCH_SIZE/p_results.db")
     w = counters(f"{src}/pmc_WRITE_SIZE/p_results.db")
     note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), "
-            "bench.py --steps 8 --warmup 1 --no-full-run: 8 batches of the engine-chosen schedule (six of 16384 vectors, two of 8192) "
+            "bench.py --steps 8 --warmup 1 --no-full-run: 8 batches of the engine-chosen schedule (six of 32768 vectors, two of 8192) "
             "spread over the 10 M-iteration schedule (radius 128 -> 17); FETCH_SIZE x2 (gfx950), per-launch averages")
-    bdesc = "engine-chosen (16384 over the first three quarters of the schedule, 8192 after)"
+    bdesc = "engine-chosen (32768 over the first three quarters of the schedule, 8192 after)"
     res = {}
     for k in sorted(set(f) | set(w)):
         rd = 2.0 * f.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
