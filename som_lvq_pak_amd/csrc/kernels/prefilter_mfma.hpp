@@ -888,7 +888,7 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1w(CbView cb, int d8
 template <int BD_KB>
 __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1w16(CbView cb, int d8, const uint4 *__restrict__ chi,
                                                                  const uint4 *__restrict__ xhi, const float *__restrict__ cn,
-                                                                 int64_t bpad, float *__restrict__ wmin) {
+                                                                 int64_t bpad, float *__restrict__ wmin, int ntx, int nty) {
   static_assert(BD_KB == 4, "one K-step of 32 dims per stage");
   constexpr int CH = 0, XH = 4 * BD_KB * 64, TOT = XH + 8 * BD_KB * 32;
   __shared__ uint4 lds[2 * TOT];
@@ -899,8 +899,22 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1w16(CbView cb, int 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;                // this wave multiplies code group wr x sample tiles 4 wc .. 4 wc + 3
   const int kg = lane >> 4, l15 = lane & 15;
-  const int64_t g0 = static_cast<int64_t>(blockIdx.y) * 4;
-  const int64_t st0 = static_cast<int64_t>(blockIdx.x) * 8;
+  // 1-D grid over the ntx (256-sample columns) x nty (256-code blocks) tiles, in SUPER-COLUMNS of L1_SC columns: all code
+  // blocks of 64 columns (16384 samples) before the next 64.  Workgroups go to the 8 XCDs round-robin, so an XCD multiplies
+  // every 8th column; with the columns of a super-column only, the sample tiles it keeps re-reading are 8 x 256 KiB --
+  // they stay in its 4 MiB L2 next to the code block in hand.  (Plain x-fastest order over 128 columns of a 32768-vector
+  // batch: 16 columns = 4 MiB per XCD, and 3.3 GB per launch came from beyond L2 instead of 0.5.)
+  constexpr int L1_SC = 64;
+  int tx, ty;
+  {
+    const int lin = blockIdx.x, per_sc = L1_SC * nty;
+    const int sc = lin / per_sc, rem = lin - sc * per_sc;
+    const int cols = ntx - sc * L1_SC < L1_SC ? ntx - sc * L1_SC : L1_SC;   // the last super-column may be narrower
+    ty = rem / cols;
+    tx = sc * L1_SC + rem - ty * cols;
+  }
+  const int64_t g0 = static_cast<int64_t>(ty) * 4;
+  const int64_t st0 = static_cast<int64_t>(tx) * 8;
   const int64_t nst = bpad / 32;
   const int arr = wave & 1, sel = wave >> 1;
   const int64_t gsrc = g0 + sel < cb.ngroups ? g0 + sel : cb.ngroups - 1;
