@@ -987,13 +987,14 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1w16(CbView cb, int 
 }
 
 // survivors of level 1, gathered by row group: list[g][0 .. cnt[g]) = the samples b with wmin1[g][b] <= gmin1[b] + tau1[b].
-// Grid: (32-sample columns, chunks of groups), as the re-rank's select.
+// Grid: (256-sample columns, chunks of groups); thread = sample, a wave = 64 consecutive samples of one group per trip
+// (256 contiguous bytes of wmin; four groups' loads in flight), one list reservation per wave and group.
 __global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t count, int64_t bpad, int64_t chunk,
                                                    const float *__restrict__ wmin, const uint32_t *__restrict__ gmin1,
                                                    const float *__restrict__ tau1, uint32_t *__restrict__ cnt,
                                                    uint16_t *__restrict__ list) {
-  const int tid = threadIdx.x, bx = tid & 31, gy = tid >> 5, lane = tid & 63;
-  const int64_t b = static_cast<int64_t>(blockIdx.x) * 32 + bx;
+  const int lane = threadIdx.x & 63;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   const int64_t g_lo = static_cast<int64_t>(blockIdx.y) * chunk;
   const int64_t g_hi = g_lo + chunk < ngroups ? g_lo + chunk : ngroups;
   float thr = -3.4e38f;
@@ -1001,16 +1002,22 @@ __global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t coun
     const uint32_t o = gmin1[b];                         // order-preserving image of the float minimum (float_to_ordered)
     thr = __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o) + tau1[b];
   }
-  // a half-wave (32 samples) looks at one group per trip: one reservation per half-wave and group, not one per survivor
-  for (int64_t g0 = g_lo; g0 < g_hi; g0 += 8) {
-    const int64_t g = g0 + gy;
-    const bool in = g < g_hi && b < count && wmin[g * bpad + b] <= thr;
-    const unsigned long long bal = __ballot(in);
-    const uint32_t mine = static_cast<uint32_t>(lane < 32 ? bal : bal >> 32);
-    uint32_t base = 0;
-    if (bx == 0 && mine) base = atomicAdd(&cnt[g], static_cast<uint32_t>(__popc(mine)));
-    base = __shfl(base, lane & 32, WAVE);
-    if (in) list[g * bpad + base + __popc(mine & ((1u << bx) - 1u))] = static_cast<uint16_t>(b);
+  const bool live = b < count;                           // (count <= bpad: the loads stay inside the rows of wmin)
+  for (int64_t g0 = g_lo; g0 < g_hi; g0 += 4) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (live && g0 + k < g_hi) ? wmin[(g0 + k) * bpad + b] : 3.4e38f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool in = v[k] <= thr;
+      const unsigned long long bal = __ballot(in);
+      if (bal == 0ull) continue;
+      const int64_t g = g0 + k;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&cnt[g], static_cast<uint32_t>(__popcll(bal)));
+      base = __shfl(base, 0, WAVE);
+      if (in) list[g * bpad + base + __popcll(bal & ((1ull << lane) - 1ull))] = static_cast<uint16_t>(b);
+    }
   }
 }
 
