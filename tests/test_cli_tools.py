@@ -515,6 +515,24 @@ def test_vsom_gpus_flag_equals_one_gpu(tools, tmp_path):
 
 
 @pytest.mark.gpu
+def test_vsom_batch_auto(tools, tmp_path):
+    """vsom -batch auto: the engine's own batch boundaries (somhip_som_auto_batch) -- the bytes of the same run made in
+    two explicit segments' worth of fixed batches are not reachable from the command line, so: one GPU == three ranks
+    (every rank asks the library for the same boundaries), and != a fixed -batch 4096 run (the schedule really differs)."""
+    g = "gen:k=6,dim=8,n=20000,seed=5"
+    init = tmp_path / "a_init.cod"
+    run("randinit", "-din", g, "-cout", init, "-xdim", 16, "-ydim", 16, "-topol", "hexa", "-neigh", "bubble", "-rand", 4, "-v", 0)
+    L = 32 * 32768 + 5000
+    common = ["-din", g, "-cin", init, "-rlen", L, "-alpha", 0.05, "-radius", 8, "-v", 0]
+    a, b, c = tmp_path / "auto1.cod", tmp_path / "auto3.cod", tmp_path / "fixed.cod"
+    run("vsom", *common, "-batch", "auto", "-cout", a)
+    run("vsom", *common, "-batch", "auto", "-cout", b, "-gpus", 3)
+    run("vsom", *common, "-batch", 4096, "-cout", c)
+    assert md5(a) == md5(b)
+    assert md5(a) != md5(c)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["lvq1", "lvq2", "lvq3", "olvq1", "olvq1_default"])
 def test_lvqtrain_gpus_flag_gives_the_reference_bytes(tools, tmp_path, tag):
     """lvqtrain -gpus 3: the codebook's rows cut into three blocks, one process each (sharing this box's GPU: candidate
