@@ -1157,8 +1157,8 @@ def test_gemm_update_mode_gaussian(eng, E, oracle, xd, yd, d, B, radius, alpha, 
 
 
 def test_gemm_update_mode_falls_back_and_shards_identically(eng, E, oracle):
-    """gemm mode is taken only where it applies (bubble, no masks, dim % 128 == 0): a dim-48 map, a gaussian map and
-    masked data must give the exact kernels' bits; interleaved shards in gemm mode give the unsharded gemm bits."""
+    """gemm mode is taken only where it applies (no masks, dim % 128 == 0): dim-48 maps (bubble and gaussian) must give the
+    exact kernels' bits; interleaved shards in gemm mode -- bubble and gaussian -- give the unsharded gemm bits."""
     from som_lvq_pak_amd._lib import SomParams
     eng.set_update_mode("gemm")
     try:
@@ -1170,36 +1170,39 @@ def test_gemm_update_mode_falls_back_and_shards_identically(eng, E, oracle):
             E.som_train(cb, ds, 600, 0.05, 5.0, batch=100, trace=False)
             assert np.array_equal(bits(cb.download()), bits(want)), neigh
             cb.close(); ds.close()
-        # sharded == unsharded, gemm kernels on both sides
+        # sharded == unsharded, gemm kernels on both sides (bubble, and gaussian: the dense-weight form)
         d, n, B, xd, yd = 128, 2048, 512, 32, 24
         ds = E.Dataset(eng, generate=(5, 8, d, 0, n))
         lo, hi, cnt = E.column_minmax(ds)
         ini = E.randinit_from_bbox(lo, hi, cnt, xd, yd, 9)
-        cb = E.Codebook(eng, ini, 3, 1, xd, yd)
-        E.som_train(cb, ds, 2 * B, 0.05, 10.0, batch=B, trace=False)
-        whole = cb.download()
-        shards = []
-        for r in range(3):
-            units = E.shard_units(xd, yd, r, 3, eng.lib)
-            shards.append((units, E.Codebook(eng, ini[units], 3, 1, xd, yd, interleave=(r, 3))))
-        kb = eng.device_alloc(8 * B)
-        p = SomParams(2 * B, 0.05, 10.0, 1, 0, 0, B, 0, 2 * B, 0)
-        for it0 in range(0, 2 * B, B):
-            ks = []
-            for _, s in shards:
-                E.check(eng.lib.somhip_batch_winner_keys(s.h, ds.h, it0, B, kb))
-                k = np.empty(B, dtype=np.uint64)
-                E.check(eng.lib.somhip_copy_to_host(eng.h, k.ctypes.data_as(C.c_void_p), kb, 8 * B))
-                ks.append(k)
-            merged = np.minimum(np.minimum(ks[0], ks[1]), ks[2])
-            E.check(eng.lib.somhip_copy_to_device(eng.h, kb, merged.ctypes.data_as(C.c_void_p), 8 * B))
-            for _, s in shards:
-                E.check(eng.lib.somhip_som_batch_update(s.h, ds.h, C.byref(p), it0, B, it0, kb))
-        eng.sync()
-        eng.device_free(kb)
-        full = np.empty_like(whole)
-        for units, s in shards:
-            full[units] = s.download()
-        assert np.array_equal(bits(full), bits(whole))
+        for neigh in (1, 2):
+            cb = E.Codebook(eng, ini, 3, neigh, xd, yd)
+            s0 = eng.scan_stats()
+            E.som_train(cb, ds, 2 * B, 0.05, 10.0, batch=B, trace=False)
+            assert eng.scan_stats()["gemm_entries"] > s0["gemm_entries"], neigh
+            whole = cb.download()
+            shards = []
+            for r in range(3):
+                units = E.shard_units(xd, yd, r, 3, eng.lib)
+                shards.append((units, E.Codebook(eng, ini[units], 3, neigh, xd, yd, interleave=(r, 3))))
+            kb = eng.device_alloc(8 * B)
+            p = SomParams(2 * B, 0.05, 10.0, 1, 0, 0, B, 0, 2 * B, 0)
+            for it0 in range(0, 2 * B, B):
+                ks = []
+                for _, s in shards:
+                    E.check(eng.lib.somhip_batch_winner_keys(s.h, ds.h, it0, B, kb))
+                    k = np.empty(B, dtype=np.uint64)
+                    E.check(eng.lib.somhip_copy_to_host(eng.h, k.ctypes.data_as(C.c_void_p), kb, 8 * B))
+                    ks.append(k)
+                merged = np.minimum(np.minimum(ks[0], ks[1]), ks[2])
+                E.check(eng.lib.somhip_copy_to_device(eng.h, kb, merged.ctypes.data_as(C.c_void_p), 8 * B))
+                for _, s in shards:
+                    E.check(eng.lib.somhip_som_batch_update(s.h, ds.h, C.byref(p), it0, B, it0, kb))
+            eng.sync()
+            eng.device_free(kb)
+            full = np.empty_like(whole)
+            for units, s in shards:
+                full[units] = s.download()
+            assert np.array_equal(bits(full), bits(whole)), neigh
     finally:
         eng.set_update_mode("exact")
