@@ -58,7 +58,7 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
                                                      int xoff_scale = 0, uint32_t tail_need = 0,
                                                      uint32_t *__restrict__ lstart = nullptr, int gauss_gemm = 0) {
   // gauss_gemm (GAUSS only; the consumer is K4m's gaussian form): the entry's mask field carries the winner's lattice
-  // coordinates (x | y << 16) and, in its upper word, the float log2(e) / (2 radius^2) of the iteration; samples whose
+  // coordinates (x | y << 10, 10 bits each), 8 bits of remainder of, and in its upper word the float log2(e) / (2 radius^2) of the iteration; samples whose
   // rate would be below 2^-40 of alpha for every unit of the group are left out
   // xoff_first >= 0 (the consumer is K4s): the entry carries, instead of the sample's index in the run, where its
   // row starts in the data array in float4 units -- ((xoff_first + index) mod xoff_rows) * d / 4 -- so that the
@@ -133,10 +133,13 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
           const double lat_min = fx * fx + 0.75 * static_cast<double>(ddy) * ddy;
           const double coef = 1.4426950408889634 / (2.0 * static_cast<double>(s.thresh) * static_cast<double>(s.thresh));
           if (lat_min * coef <= 40.0) {
+            // coef as a float + the remainder in units of 2^-32 coef (8 signed bits): the exponent reaches ~40, and a
+            // float's 2^-24 on it would put 2e-6 into every rate -- a bias that adds up over thousands of hits
             const float cf = static_cast<float>(coef);
-            m = (static_cast<unsigned long long>(__float_as_uint(cf)) << 32) |
-                (static_cast<unsigned long long>(static_cast<uint32_t>(w.y) & 0xFFFFu) << 16) | (static_cast<uint32_t>(w.x) & 0xFFFFu);
-            if (m == 0ull) m = 1ull << 63;               // (cannot happen: coef > 0)
+            int rq = static_cast<int>(rint((coef - static_cast<double>(cf)) / (static_cast<double>(cf) * 2.3283064365386963e-10)));
+            rq = rq < -128 ? -128 : rq > 127 ? 127 : rq;
+            m = (static_cast<unsigned long long>(__float_as_uint(cf)) << 32) | (static_cast<unsigned long long>(rq & 0xFF) << 20) |
+                (static_cast<unsigned long long>(static_cast<uint32_t>(w.y) & 0x3FFu) << 10) | (static_cast<uint32_t>(w.x) & 0x3FFu);
           }
         } else if (GAUSS) m = live_mask;
         else if (cb.patch_w && small_map) {
