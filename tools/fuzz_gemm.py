@@ -91,7 +91,7 @@ def main():
         n += 1
         if n % 20 == 0:
             print("%d cases, worst error of the gemm result against the float64 replay %.2e of the scale" % (n, worst), flush=True)
-    print("fuzz gemm ok: %d cases in %.0f s, worst error of the gemm result against a float64 replay %.2e of the scale (never above twice the exact kernels' own)" % (n, time.time() - t0, worst))
+    print("fuzz gemm ok: %d cases in %.0f s, worst error of the gemm result against a float64 replay %.2e of the scale (bound per case: 12 sqrt(hits) 2^-24, or twice the exact kernels' own error)" % (n, time.time() - t0, worst))
 
 
 if __name__ == "__main__":
