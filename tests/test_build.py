@@ -31,6 +31,34 @@ def test_header_symbols_exported(built):
     assert lib.somhip_version() == 1
 
 
+def test_auto_batch_schedule_is_host_arithmetic(built):
+    """somhip_som_auto_batch (the engine's own mini-batch boundaries, SOMHIP_BATCH_AUTO) is plain host arithmetic: it must
+    answer without a GPU, cut a schedule into contiguous batches that end exactly at its length, and refuse nonsense."""
+    import ctypes as C
+    from som_lvq_pak_amd import _lib
+    lib = _lib.load()
+
+    def ab(length, it):
+        a, b = C.c_int64(0), C.c_int64(0)
+        rc = lib.somhip_som_auto_batch(length, it, C.byref(a), C.byref(b))
+        return rc, a.value, b.value
+
+    for length in (1, 4095, 100000, 32 * 32768, 10_000_000):
+        it, sizes = 0, []
+        while it < length:
+            rc, st, ln = ab(length, it)
+            assert rc == 0 and st == it and 0 < ln <= 32768 and st + ln <= length
+            assert ab(length, st + ln - 1)[1:] == (st, ln)          # every iteration of the batch names the same batch
+            sizes.append(ln)
+            it = st + ln
+        assert it == length
+        if length >= 32 * 32768:                                    # long batches first, short ones over the last quarter
+            assert sizes[0] == 32768 and sizes[-2] == 8192 and sorted(sizes[:-1], reverse=True) == sizes[:-1]
+        else:
+            assert max(sizes) <= 4096
+    assert ab(1000, 1000)[0] != 0 and ab(0, 0)[0] != 0 and ab(1000, -1)[0] != 0
+
+
 def test_no_cpu_fallback(built):
     """without a GPU the engine must refuse, not silently compute on the host"""
     import torch
