@@ -446,7 +446,9 @@ def bench_som(a):
                        "alpha": a.alpha, "radius": radius, "alpha_type": "linear",
                        "stream": "gen:k=%d,dim=%d,n=%d,seed=%d (somhip_dataset_generate); randinit -rand %d" % (kcent, d, L, seed, init_seed),
                        "schedule": sched, "update_mode": a.update,
-                       "parallelism": "codebook sharded (%s), all-reduce(MIN) of (dist,idx) keys" % layout
+                       "parallelism": "codebook sharded (%s), %sall-reduce(MIN) of (dist,idx) keys"
+                                      % (layout, "pre-filter bounds MIN-reduced between the levels of the winner search, "
+                                         if any(ssom._exch.values()) else "")
                        if world > 1 else "single GPU",
                        "commit": git_head()},
             "value_timed_steps": value_steps,

@@ -252,6 +252,29 @@ int  somhip_batch_winner_keys(somhip_codebook *cb, somhip_dataset *ds, int64_t f
 int  somhip_som_batch_update(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
                              int64_t batch_start_iter, int64_t count, int64_t data_first,
                              const uint64_t *dev_keys);
+/* The same search over a ROW-SHARDED codebook with the pre-filter's bounds exchanged between the shards (find_winner_euc,
+ * lvq_pak.c:41-96, over rows that live on several GPUs).  somhip_batch_winner_keys on a shard keeps every row group
+ * within a window of the SHARD's smallest pre-filter value, so N shards together re-rank N times what one GPU would;
+ * with the smallest bound of all shards in its place they re-rank what the whole codebook's search would:
+ *     somhip_shard_winner_begin    level 1 of the pre-filter; dev_bound[count] (DEVICE floats) <- an upper bound on
+ *                                  (squared distance to the nearest row of this shard) - ||x||^2; presets dev_keys
+ *     host: all-reduce(MIN) of dev_bound as floats
+ *     somhip_shard_winner_refine   level 2 for the groups within the exchanged bound; dev_bound <- the tighter bound
+ *     host: all-reduce(MIN) of dev_bound
+ *     somhip_shard_winner_finish   exact re-rank of the rows within the bound; dev_keys as somhip_batch_winner_keys
+ *                                  (a shard that holds no candidate for a sample leaves 0x7FFFFFFFFFFFFFFF)
+ *     host: all-reduce(MIN) of dev_keys, then somhip_som_batch_update
+ * After the last all-reduce the keys are bit-identical to those of somhip_batch_winner_keys + all-reduce (the bounds only
+ * remove rows that provably cannot win).  The three calls of one search share the engine's scratch memory: nothing else
+ * may run on the engine between them.  somhip_shard_exchange_available: 1 if this shape takes the path (bf16 pre-filter,
+ * dim a multiple of 32, 225 <= count <= 65504, no masks), else 0 -- every rank must take the same path, so a host
+ * all-reduces the answer (MIN) once per run. */
+int  somhip_shard_exchange_available(somhip_codebook *cb, somhip_dataset *ds, int64_t count);
+int  somhip_shard_winner_begin(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
+                               uint64_t *dev_keys, float *dev_bound);
+int  somhip_shard_winner_refine(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count, float *dev_bound);
+int  somhip_shard_winner_finish(somhip_codebook *cb, somhip_dataset *ds, int64_t first, int64_t count,
+                                const float *dev_bound, uint64_t *dev_keys);
 /* k-NN over a row-sharded codebook (the X2 exchange): dev_keys[count][knn] (knn = 1, 2, 4 or 8) =
  * this shard's knn best rows per sample, ascending; tag = global row index (SOMHIP_TIE_FIRST) or its
  * bitwise complement (SOMHIP_TIE_KNN: on equal distances the LATER row sorts first, lvq_pak.c:197).
@@ -305,6 +328,7 @@ int  somhip_comm_unique_id(void *id128);
 int  somhip_comm_create(somhip_engine *e, const void *id128, int rank, int world, somhip_comm **out);
 int  somhip_comm_create_sockets(somhip_engine *e, int rank, int world, const int *fds, somhip_comm **out);
 int  somhip_comm_allreduce_min_keys(somhip_comm *c, uint64_t *dev_keys, int64_t count);
+int  somhip_comm_allreduce_min_f32(somhip_comm *c, float *dev_values, int64_t count);   /* the bounds of somhip_shard_winner_* */
 int  somhip_comm_allreduce_sum_u32(somhip_comm *c, uint32_t *dev_words, int64_t count);
 int  somhip_comm_allgather(somhip_comm *c, const void *dev_send, void *dev_recv, int64_t bytes_per_rank);
 void somhip_comm_destroy(somhip_comm *c);

@@ -73,6 +73,10 @@ SIGNATURES = {
     "somhip_lvq_train": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(LvqParams), c_float_p, c_i32_p,
                                    c_float_p]),
     "somhip_batch_winner_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "somhip_shard_exchange_available": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "somhip_shard_winner_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "somhip_shard_winner_refine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "somhip_shard_winner_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "somhip_batch_topk_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "somhip_merge_topk_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "somhip_lvq_rates_upload": (C.c_int, [C.c_void_p, c_float_p]),
@@ -86,6 +90,7 @@ SIGNATURES = {
     "somhip_comm_create_sockets": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
     "somhip_comm_allreduce_min_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "somhip_comm_allreduce_sum_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "somhip_comm_allreduce_min_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "somhip_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "somhip_comm_destroy": (None, [C.c_void_p]),
     "somhip_som_batch_update": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SomParams), C.c_int64,

@@ -66,7 +66,9 @@ struct RerankInit {
 __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int d, int64_t first,
                              int64_t count, const unsigned int *__restrict__ cn_max_bits,
                              double err_prod, double err_sq, float *__restrict__ tau, RerankInit init,
-                             double l1_prod = 0.0, double l1_sq = 0.0, float *__restrict__ tau1 = nullptr) {
+                             double l1_prod = 0.0, double l1_sq = 0.0, float *__restrict__ tau1 = nullptr,
+                             float *__restrict__ xw = nullptr) {
+  // xw (shard exchange, K2x below): [0, bpad) delta1, [bpad, 2 bpad) max(delta1, 3 delta3), [2 bpad, 3 bpad) delta3, each rounded up
   const int64_t b = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (init.gmin) {                                       // 64 * count threads >= bpad + 4 * ncols
@@ -108,6 +110,12 @@ __global__ void k_sample_tau(const float *__restrict__ rows, int64_t n_rows, int
       float t1f = static_cast<float>(t1);
       if (static_cast<double>(t1f) < t1) t1f = __uint_as_float(__float_as_uint(t1f) + 1);
       tau1[b] = t1f;
+      if (xw) {
+        auto up = [](double v) { float f = static_cast<float>(v); if (static_cast<double>(f) < v) f = __uint_as_float(__float_as_uint(f) + 1); return f; };
+        xw[b] = up(d1);
+        xw[init.bpad + b] = up(d1 > 3.0 * d3 ? d1 : 3.0 * d3);
+        xw[2 * init.bpad + b] = up(d3);
+      }
     }
   }
 }
@@ -992,7 +1000,10 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1w16(CbView cb, int 
 __global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t count, int64_t bpad, int64_t chunk,
                                                    const float *__restrict__ wmin, const uint32_t *__restrict__ gmin1,
                                                    const float *__restrict__ tau1, uint32_t *__restrict__ cnt,
-                                                   uint16_t *__restrict__ list) {
+                                                   uint16_t *__restrict__ list, float *__restrict__ mark = nullptr) {
+  // mark (= wmin; shard exchange): a (group, sample) pair that is left out gets the value 3.4e38 in place of its level-1
+  // minimum -- with a bound from another shard a shard may keep no group at all for a sample, and what is left out must
+  // never look like a candidate to the re-rank
   const int lane = threadIdx.x & 63;
   const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   const int64_t g_lo = static_cast<int64_t>(blockIdx.y) * chunk;
@@ -1011,8 +1022,9 @@ __global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t coun
     for (int k = 0; k < 4; k++) {
       const bool in = v[k] <= thr;
       const unsigned long long bal = __ballot(in);
-      if (bal == 0ull) continue;
       const int64_t g = g0 + k;
+      if (mark && live && g < g_hi && !in) mark[g * bpad + b] = 3.4e38f;
+      if (bal == 0ull) continue;
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(&cnt[g], static_cast<uint32_t>(__popcll(bal)));
       base = __shfl(base, 0, WAVE);

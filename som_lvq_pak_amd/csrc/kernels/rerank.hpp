@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void k_rerank(CbView cb, const float *__restri
   unsigned ngroups_done = 0, nrows_done = 0;
   for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
     const int64_t gl = gb + lane;
-    const bool q = gl < cb.ngroups && wmin[gl * bpad + b] <= thr;
+    const float wv = gl < cb.ngroups ? wmin[gl * bpad + b] : 3.4e38f;
+    const bool q = wv <= thr && wv < 3.0e38f;              // (3.4e38: left out by k_l2_select under a shard-exchange bound)
     uint64_t ball = __ballot(q);
     while (ball) {
       const int t = __builtin_ctzll(ball);
@@ -375,6 +376,38 @@ __device__ __forceinline__ uint32_t float_to_ordered(float f) {
 }
 __device__ __forceinline__ float ordered_to_float(uint32_t u) {
   return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
+
+// K2x: the winner search of a row-sharded codebook with the pre-filter's bounds exchanged between the shards
+// (somhip_shard_winner_begin / _refine / _finish).  A shard on its own keeps every group within a window of ITS smallest
+// level-1 value, so N shards together keep N times what one codebook would; with the smallest upper bound of all shards
+// instead, the shards together keep what the whole codebook would keep.
+//   ub[b] = (this shard's smallest pre-filter value) + delta: the exact nearest row of the WHOLE codebook has s <= ub for
+//   every shard's ub (s = distance - ||x||^2, the same on every shard), hence <= the MIN over the shards; in its own shard
+//   its pre-filter value is <= that MIN + delta(shard).  The deltas are each shard's own (its largest row norm).
+__global__ void k_shard_bound(int64_t count, const uint32_t *__restrict__ gmin, const float *__restrict__ delta,
+                              float *__restrict__ ub) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (b >= count) return;
+  const uint32_t o = gmin[b];
+  float v = 3.4e38f;
+  if (o != 0xFFFFFFFFu) {
+    const float m = __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);      // (= ordered_to_float)
+    if (m < 3.0e38f) {
+      v = m + delta[b];
+      v += fabsf(v) * 1.2e-7f;                           // the sum rounded up
+    }
+  }
+  ub[b] = v;
+}
+// the exchanged bound takes the place of the shard's own minimum (ordered image), the window that of the shard's own
+__global__ void k_shard_apply(int64_t count, const float *__restrict__ ub, uint32_t *__restrict__ gmin,
+                              const float *__restrict__ window, float *__restrict__ win_out) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (b >= count) return;
+  const uint32_t u = __float_as_uint(ub[b]);
+  gmin[b] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // (= float_to_ordered)
+  if (win_out) win_out[b] = window[b];
 }
 
 // K2m: gmin[b] = min over the shard's row groups of the group minima (ordered-uint encoding; the

@@ -1002,7 +1002,8 @@ done:
  * One process per GPU: the parent -- which has parsed the arguments and read the files, and has not
  * touched a GPU -- forks G ranks; rank r takes device r % (visible GPUs), holds every G-th 8x8-unit patch of the map
  * (somhip_codebook_create_interleaved; contiguous row blocks when a map side is not a multiple of 8) and the whole
- * data set.  Per mini-batch: somhip_batch_winner_keys on its shard -> somhip_comm_allreduce_min_keys (RCCL
+ * data set.  Per mini-batch: somhip_batch_winner_keys on its shard (or somhip_shard_winner_begin / refine / finish with
+ * the pre-filter's bounds MIN-reduced between them) -> somhip_comm_allreduce_min_keys (RCCL
  * ncclAllReduce(ncclUint64, ncclMin) on the engine's stream; the ranks get the communicator id from rank 0 over a
  * socketpair the parent made) -> somhip_som_batch_update of its own rows.  The codebook comes together only at the end
  * (X3), on rank 0, which returns it for saving.  When the ranks outnumber the GPUs (a rehearsal on one GPU: RCCL
@@ -1025,7 +1026,7 @@ static int som_training_rank(struct teach_params *teach, int rank, int world, in
   somhip_comm *comm = NULL;
   somhip_codebook *cb = NULL;
   somhip_dataset *ds = NULL;
-  void *dkeys = NULL;
+  void *dkeys = NULL, *dbound = NULL, *dflag = NULL;
   int64_t *units = NULL, n_local = 0;
   float *mine = NULL;
   if (pak_rank_device(rank) < 0 || somhip_device_count(&ndev)) return 1;
@@ -1061,7 +1062,9 @@ static int som_training_rank(struct teach_params *teach, int rank, int world, in
   if (interleaved ? somhip_codebook_create_interleaved(en, mine, n_local, (int)dim, codes->topol, codes->neigh, codes->xdim, codes->ydim, rank, world, &cb)
                   : somhip_codebook_create(en, mine, NULL, n_local, (int)dim, codes->topol, codes->neigh, codes->xdim, codes->ydim, units[0], n, &cb)) goto hip_fail;
   if (!(ds = mirror_data(data, 0))) goto done;
-  if (somhip_device_alloc(en, 8 * B, &dkeys)) goto hip_fail;
+  if (somhip_device_alloc(en, 8 * B, &dkeys) || somhip_device_alloc(en, 4 * B, &dbound) || somhip_device_alloc(en, 16, &dflag)) goto hip_fail;
+  long exch_c = -1;
+  int exch_ok = 0;
 
   somhip_som_params sp = { L, teach->alpha, teach->radius, teach->alpha_type, use_fixed_level, use_weights_level, B, 0, 0, 0 };
   for (long it0 = 0; it0 < L;) {                       /* batches aligned to the schedule, as somhip_som_train cuts them */
@@ -1072,8 +1075,21 @@ static int som_training_rank(struct teach_params *teach, int rank, int world, in
       if (somhip_som_auto_batch(L, it0, &bs, &bl)) goto hip_fail;
       c = (long)(bs + bl - it0);
     }
-    if (somhip_batch_winner_keys(cb, ds, first, c, dkeys) || somhip_comm_allreduce_min_keys(comm, dkeys, c) ||
-        somhip_som_batch_update(cb, ds, &sp, it0, c, first, dkeys)) goto hip_fail;
+    if (c != exch_c) {                                 /* every rank has to take the same path: the answers are summed once per batch length */
+      uint32_t f = world > 1 && somhip_shard_exchange_available(cb, ds, c) ? 1u : 0u;
+      if (somhip_copy_to_device(en, dflag, &f, sizeof f) || somhip_comm_allreduce_sum_u32(comm, dflag, 1) ||
+          somhip_copy_to_host(en, &f, dflag, sizeof f)) goto hip_fail;
+      exch_ok = f == (uint32_t)world;
+      if (exch_ok && exch_c < 0 && rank == 0) ifverbose(2) fprintf(stderr, "winner search: pre-filter bounds exchanged between the %d ranks\n", world);
+      exch_c = c;
+    }
+    /* the winner search of the whole map: with the pre-filter's bounds going round between its levels every rank
+     * re-ranks only what one GPU holding the whole map would (somhip.h, somhip_shard_winner_*) */
+    if (exch_ok ? (somhip_shard_winner_begin(cb, ds, first, c, dkeys, dbound) || somhip_comm_allreduce_min_f32(comm, dbound, c) ||
+                   somhip_shard_winner_refine(cb, ds, first, c, dbound) || somhip_comm_allreduce_min_f32(comm, dbound, c) ||
+                   somhip_shard_winner_finish(cb, ds, first, c, dbound, dkeys))
+                : somhip_batch_winner_keys(cb, ds, first, c, dkeys)) goto hip_fail;
+    if (somhip_comm_allreduce_min_keys(comm, dkeys, c) || somhip_som_batch_update(cb, ds, &sp, it0, c, first, dkeys)) goto hip_fail;
     it0 += c;
   }
   if (somhip_codebook_download(cb, mine)) goto hip_fail;
@@ -1098,6 +1114,8 @@ hip_fail:
   fprintf(stderr, "som_training (rank %d): %s\n", rank, somhip_last_error());
 done:
   if (dkeys) somhip_device_free(en, dkeys);
+  if (dbound) somhip_device_free(en, dbound);
+  if (dflag) somhip_device_free(en, dflag);
   if (ds) somhip_dataset_destroy(ds);
   if (cb) somhip_codebook_destroy(cb);
   if (comm) somhip_comm_destroy(comm);

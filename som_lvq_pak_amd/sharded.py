@@ -59,6 +59,19 @@ def allreduce_min_keys(keys, group=None, nonnegative=False):
     return keys
 
 
+def allreduce_min_floats(t, group=None):
+    """Element-wise MIN of a float32 tensor over all ranks, in place (the exchanged pre-filter bounds)."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        else:
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
+            t.copy_(host)
+    return t
+
+
 def allgather_topk_keys(keys, knn, group=None):
     """X2: `keys` = this rank's [count, knn] packed keys (uint64 numpy or int64 torch tensor, ascending);
     returns the knn smallest per sample over all ranks as a uint64 numpy array [count, knn].  Keys are
@@ -140,13 +153,43 @@ class ShardedSom:
         self.shard = shard
         self.batch = batch
         self.n_data = n_data
+        self._exch = {}
 
     def step(self, it0, data_first, count):
-        keys = self.shard.winner_keys(data_first, count)
+        if self._exchange(count):
+            # the pre-filter's bounds go round between its levels (somhip.h, somhip_shard_winner_*): three small
+            # all-reduces in place of one, and every shard re-ranks only what the whole codebook's search would
+            bound = self.shard.winner_begin(data_first, count)
+            with self.shard.collective_scope():
+                allreduce_min_floats(bound)
+            self.shard.winner_refine(data_first, count)
+            with self.shard.collective_scope():
+                allreduce_min_floats(bound)
+            keys = self.shard.winner_finish(data_first, count)
+        else:
+            keys = self.shard.winner_keys(data_first, count)
         with self.shard.collective_scope():
             allreduce_min_keys(keys, nonnegative=getattr(self.shard, "keys_nonnegative", False))
         self.shard.update(it0, count, data_first, keys)
         return keys
+
+    def _exchange(self, count):
+        """Every rank has to take the same path: the shards' answers are MIN-reduced once per batch length."""
+        if not hasattr(self.shard, "exchange_available"):
+            return False
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return False                                  # one shard: its own minimum IS the whole codebook's
+        if count not in self._exch:
+            ok = 1 if self.shard.exchange_available(count) else 0
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+                t = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok = int(t.item())
+            self._exch[count] = bool(ok)
+        return self._exch[count]
 
     def train(self, length, start_iter=0, count=None, data_first=None):
         count = length - start_iter if count is None else count
@@ -174,12 +217,40 @@ class GpuShard:
         self.e, self.cb, self.ds = engine, codebook, dataset
         self.params_factory = params_factory
         self.keys = torch.empty(max_batch, dtype=torch.int64, device=torch.device("cuda", engine.device))
+        self.bound = torch.empty(max_batch, dtype=torch.float32, device=torch.device("cuda", engine.device))
 
     def winner_keys(self, first, count):
         import ctypes as C
         from ._lib import check
         check(self.e.lib.somhip_batch_winner_keys(self.cb.h, self.ds.h, first, count,
                                                   C.c_void_p(self.keys.data_ptr())))
+        return self.keys[:count]
+
+    # the same search with the pre-filter's bounds exchanged between the shards (include/somhip.h)
+    def exchange_available(self, count):
+        import os
+        if os.environ.get("SOMHIP_NO_SHARD_EXCHANGE"):
+            return False
+        return bool(self.e.lib.somhip_shard_exchange_available(self.cb.h, self.ds.h, count))
+
+    def winner_begin(self, first, count):
+        import ctypes as C
+        from ._lib import check
+        check(self.e.lib.somhip_shard_winner_begin(self.cb.h, self.ds.h, first, count, C.c_void_p(self.keys.data_ptr()),
+                                                   C.c_void_p(self.bound.data_ptr())))
+        return self.bound[:count]
+
+    def winner_refine(self, first, count):
+        import ctypes as C
+        from ._lib import check
+        check(self.e.lib.somhip_shard_winner_refine(self.cb.h, self.ds.h, first, count, C.c_void_p(self.bound.data_ptr())))
+        return self.bound[:count]
+
+    def winner_finish(self, first, count):
+        import ctypes as C
+        from ._lib import check
+        check(self.e.lib.somhip_shard_winner_finish(self.cb.h, self.ds.h, first, count, C.c_void_p(self.bound.data_ptr()),
+                                                    C.c_void_p(self.keys.data_ptr())))
         return self.keys[:count]
 
     def update(self, it0, count, first, keys):

@@ -306,6 +306,129 @@ def test_som_interleaved_shards_two_phase(eng, E, oracle, shape):
         eng.device_free(k)
 
 
+def _exchange_search(E, engs, shards, dss, first, count):
+    """begin -> MIN -> refine -> MIN -> finish -> MIN over shards that each live on their own engine (the three phases
+    of a search own their engine's scratch); returns the merged keys and every shard's own keys."""
+    S = len(shards)
+    kb = [engs[s].device_alloc(8 * count) for s in range(S)]
+    bb = [engs[s].device_alloc(4 * count) for s in range(S)]
+    hb = [np.empty(count, dtype=np.float32) for _ in range(S)]
+    hk = [np.empty(count, dtype=np.uint64) for _ in range(S)]
+
+    def exchange_bounds():
+        for s in range(S):
+            assert engs[s].lib.somhip_copy_to_host(engs[s].h, hb[s].ctypes.data_as(C.c_void_p), bb[s], 4 * count) == 0
+        m = np.ascontiguousarray(np.minimum.reduce(hb))
+        for s in range(S):
+            assert engs[s].lib.somhip_copy_to_device(engs[s].h, bb[s], m.ctypes.data_as(C.c_void_p), 4 * count) == 0
+        return m
+
+    for s in range(S):
+        assert engs[s].lib.somhip_shard_exchange_available(shards[s].h, dss[s].h, count) == 1
+        assert engs[s].lib.somhip_shard_winner_begin(shards[s].h, dss[s].h, first, count, kb[s], bb[s]) == 0
+    b1 = exchange_bounds()
+    for s in range(S):
+        assert engs[s].lib.somhip_shard_winner_refine(shards[s].h, dss[s].h, first, count, bb[s]) == 0
+    b2 = exchange_bounds()
+    assert (b2 <= b1).all()                                   # the three-product bound is the tighter one
+    for s in range(S):
+        assert engs[s].lib.somhip_shard_winner_finish(shards[s].h, dss[s].h, first, count, bb[s], kb[s]) == 0
+        assert engs[s].lib.somhip_copy_to_host(engs[s].h, hk[s].ctypes.data_as(C.c_void_p), kb[s], 8 * count) == 0
+    for s in range(S):
+        engs[s].device_free(kb[s])
+        engs[s].device_free(bb[s])
+    return np.ascontiguousarray(np.minimum.reduce(hk)), hk, b2
+
+
+def test_shard_winner_search_with_exchanged_bounds(E, oracle):
+    """somhip_shard_winner_begin/refine/finish over three uneven row shards, one of them nowhere near the samples (it
+    keeps no row group at all and has to abstain), exact ties across shards: after the MIN the keys are those of
+    find_winner_euc over the whole codebook, and the far shard re-ranks nothing."""
+    rs = np.random.RandomState(11)
+    d, m = 64, 480
+    x = rs.standard_normal((m, d)).astype(np.float32)
+    codes = (x[rs.randint(0, m, 1500)] + 0.5 * rs.standard_normal((1500, d))).astype(np.float32)
+    codes[600:1100] += 40.0
+    codes[1300] = codes[100] = x[7]                           # the same row in two shards: the lower index wins
+    codes[1250] = x[9]
+    want_i, want_d, _ = oracle.winners(codes, x)
+    want_i, want_d = np.asarray(want_i).reshape(-1), np.asarray(want_d).reshape(-1)
+    cuts = [0, 600, 1100, 1500]
+    engs = [E.Engine(0) for _ in cuts[1:]]
+    try:
+        dss = [E.Dataset(e, x) for e in engs]
+        shards = [E.Codebook(e, codes[a:b], row_offset=a, n_global=1500) for e, a, b in zip(engs, cuts, cuts[1:])]
+        for first, count in ((0, m), (m - 100, 300)):          # the second run wraps round the end of the data
+            merged, own, bound = _exchange_search(E, engs, shards, dss, first, count)
+            sel = (first + np.arange(count)) % m
+            assert np.array_equal((merged & np.uint64(0xFFFFFFFF)).astype(np.int64), want_i[sel])
+            assert np.array_equal((merged >> np.uint64(32)).astype(np.uint32), bits(want_d[sel]))
+            assert (own[1] == np.uint64(0x7FFFFFFFFFFFFFFF)).all()      # the far shard abstains for every sample
+            # the plain per-shard search + MIN gives the same keys
+            plain = []
+            for e, cb, ds in zip(engs, shards, dss):
+                kb = e.device_alloc(8 * count)
+                hk = np.empty(count, dtype=np.uint64)
+                assert e.lib.somhip_batch_winner_keys(cb.h, ds.h, first, count, kb) == 0
+                assert e.lib.somhip_copy_to_host(e.h, hk.ctypes.data_as(C.c_void_p), kb, 8 * count) == 0
+                e.device_free(kb)
+                plain.append(hk)
+            assert np.array_equal(np.minimum.reduce(plain), merged)
+            assert (plain[1] != np.uint64(0x7FFFFFFFFFFFFFFF)).all()    # (on its own the far shard does name its best row)
+        # shapes the two-level pre-filter does not take: refused, and the availability call says so
+        small = E.Codebook(engs[0], codes[:600, :40].copy(), row_offset=0, n_global=1500)
+        ds40 = E.Dataset(engs[0], x[:, :40].copy())
+        assert engs[0].lib.somhip_shard_exchange_available(small.h, ds40.h, m) == 0
+        assert engs[0].lib.somhip_shard_exchange_available(shards[0].h, dss[0].h, 100) == 0
+        kb, bb = engs[0].device_alloc(8 * m), engs[0].device_alloc(4 * m)
+        assert engs[0].lib.somhip_shard_winner_begin(small.h, ds40.h, 0, m, kb, bb) != 0
+        engs[0].device_free(kb)
+        engs[0].device_free(bb)
+    finally:
+        for e in engs:
+            e.close()
+
+
+@pytest.mark.parametrize("neigh", ["bubble", "gaussian"])
+def test_som_interleaved_shards_with_exchanged_bounds(E, oracle, neigh):
+    """Mini-batch SOM training over three interleaved shards with the bounds exchanged inside every winner search:
+    bit-equal to the unsharded run of the batch oracle (winners and final codebook)."""
+    from som_lvq_pak_amd._lib import SomParams
+    xdim, ydim, S, d = 24, 40, 3, 32
+    topol, nb = E.TOPOL_HEXA, (E.NEIGH_GAUSSIAN if neigh == "gaussian" else E.NEIGH_BUBBLE)
+    x, _ = synth(91, 900, d)
+    B, length = 256, 1536
+    ini = oracle.randinit(x, xdim, ydim, 5)
+    oc, oi, _ = oracle.som_train(ini, xdim, ydim, topol, nb, x, length, 0.05, 9.0, batch=B)
+    units = [E.shard_units(xdim, ydim, r, S) for r in range(S)]
+    engs = [E.Engine(0) for _ in range(S)]
+    try:
+        for e in engs:
+            e.set_update_mode("exact")
+        dss = [E.Dataset(e, x) for e in engs]
+        shards = [E.Codebook(engs[r], ini[units[r]], topol, nb, xdim, ydim, interleave=(r, S)) for r in range(S)]
+        p = SomParams(length, 0.05, 9.0, 1, 0, 0, B, 0, length, 0)
+        got_idx = []
+        kb = [engs[s].device_alloc(8 * B) for s in range(S)]
+        for it0 in range(0, length, B):
+            first = it0 % x.shape[0]
+            merged, _, _ = _exchange_search(E, engs, shards, dss, first, B)
+            got_idx.append((merged & np.uint64(0xFFFFFFFF)).astype(np.int64))
+            for s in range(S):
+                assert engs[s].lib.somhip_copy_to_device(engs[s].h, kb[s], merged.ctypes.data_as(C.c_void_p), 8 * B) == 0
+                assert engs[s].lib.somhip_som_batch_update(shards[s].h, dss[s].h, C.byref(p), it0, B, first, kb[s]) == 0
+            for e in engs:
+                e.sync()
+        assert np.array_equal(np.concatenate(got_idx), oi)
+        got = np.empty_like(oc)
+        for r in range(S):
+            got[units[r]] = shards[r].download()
+        assert np.array_equal(bits(got), bits(oc))
+    finally:
+        for e in engs:
+            e.close()
+
+
 @pytest.mark.parametrize("knn", [2, 4, 8])
 def test_knn_row_sharded_merge(eng, E, oracle, knn):
     """X2 on one GPU: three uneven row shards, each shard's k best keys per sample, union sorted --

@@ -38,6 +38,10 @@ def main():
     ap.add_argument("--ydim", type=int, default=256)
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--layout", default="interleaved", choices=["interleaved", "contiguous"])
+    ap.add_argument("--exchange", action="store_true",
+                    help="the pre-filter's bounds exchanged between the shards (somhip_shard_winner_begin/refine/finish): one engine "
+                         "per shard (the phases of a search own their engine's scratch) and a host sync after every phase, so "
+                         "the kernel sums (HIP events) are the measure here, not the wall time")
     ap.add_argument("--update", default="gemm", choices=["gemm", "exact"], help="update mode (bench.py's default: gemm)")
     a = ap.parse_args()
     import torch
@@ -63,9 +67,17 @@ def main():
     ds = E.Dataset(eng, device_ptr=data.data_ptr(), n=length, dim=d)
     ext = torch.cuda.ExternalStream(eng.stream, device=dev)
     ref_q = None
+    eng0, ds0 = eng, ds
     for V in a.shards:
         shards = []
+        engs = [eng0]
         for r in range(V):
+            if a.exchange:
+                eng = E.Engine(0) if r else eng0
+                if r:
+                    eng.set_update_mode(a.update)
+                    engs.append(eng)
+                ds = E.Dataset(eng, device_ptr=data.data_ptr(), n=length, dim=d) if r else ds0
             if a.layout == "interleaved":
                 mine = E.shard_units(a.xdim, a.ydim, r, V, eng.lib)
                 cb = E.Codebook(eng, init[mine], E.TOPOL_HEXA, E.NEIGH_BUBBLE, a.xdim, a.ydim, interleave=(r, V))
@@ -76,7 +88,38 @@ def main():
             shards.append((mine, None, cb, sharded.GpuShard(
                 eng, cb, ds, lambda: SomParams(length, 0.05, radius, E.ALPHA_LINEAR, 0, 0, B, 0, 0, 0), B)))
 
+        def sync_all():
+            for e_ in engs:
+                e_.sync()
+            torch.cuda.synchronize()
+
+        def min_into_all(ts):
+            sync_all()
+            m = ts[0].clone()
+            for o in ts[1:]:
+                torch.minimum(m, o, out=m)
+            for t_ in ts:
+                t_.copy_(m)
+            torch.cuda.synchronize()
+
+        def one_by_one(call):                             # shard after shard: kernels of different engines must not overlap,
+            out = []                                      # or the HIP events of one would time the others' work too
+            for s in shards:
+                out.append(call(s[3]))
+                s[3].e.sync()
+            return out
+
+        def step_exchange(k):
+            min_into_all(one_by_one(lambda g: g.winner_begin(k * B, B)))
+            min_into_all(one_by_one(lambda g: g.winner_refine(k * B, B)))
+            keys = one_by_one(lambda g: g.winner_finish(k * B, B))
+            min_into_all(keys)
+            one_by_one(lambda g: g.update(k * B, B, k * B, keys[0]))
+            return keys[0]
+
         def step(k):
+            if a.exchange:
+                return step_exchange(k)
             keys = [s[3].winner_keys(k * B, B) for s in shards]
             with torch.cuda.stream(ext):
                 for other in keys[1:]:
@@ -88,25 +131,31 @@ def main():
         def run(timed):
             for s in shards:
                 s[2].upload(init[s[0]])
-            eng.timing(timed)
-            eng.timing_reset()
-            eng.sync()
+            for e_ in engs:
+                e_.timing(timed)
+                e_.timing_reset()
+                e_.sync()
             t0 = time.perf_counter()
             for k in range(K):
                 step(k)
-            eng.sync()
+            for e_ in engs:
+                e_.sync()
             return time.perf_counter() - t0
 
         run(False)                       # warm-up (allocations, code objects)
         wall = run(False)
         run(True)
-        table = eng.timing_table()
-        eng.timing(False)
+        table = {}
+        for e_ in engs:
+            for kname, v in e_.timing_table().items():
+                old = table.get(kname, (0, 0.0))
+                table[kname] = (old[0] + v[0], old[1] + v[1])
+            e_.timing(False)
         ne = min(8192, length)
         ks = []
         for s in shards:
             kk = s[3].winner_keys(0, min(ne, B))
-            eng.sync()
+            s[3].e.sync()
             ks.append(kk.clone())
         torch.cuda.synchronize()
         m = ks[0]
@@ -117,13 +166,15 @@ def main():
         if ref_q is None:
             ref_q = q
         per_rank = {k: round(v[1] / (K * V) * 1e3, 2) for k, v in table.items() if v[0]}
-        print(json.dumps({"shards": V, "layout": a.layout, "rows_per_shard": len(shards[0][0]),
+        print(json.dumps({"shards": V, "layout": a.layout, "exchange": bool(a.exchange), "rows_per_shard": len(shards[0][0]),
                           "ms_per_step_per_rank": round(1e3 * wall / (K * V), 4),
                           "speedup_excl_collective": None,
                           "kernel_us_per_step_per_rank": dict(sorted(per_rank.items(), key=lambda kv: -kv[1])),
                           "kernel_sum_us": round(sum(per_rank.values()), 1),
                           "qerror": q, "same_bits_as_first": q == ref_q}))
         del shards
+        for e_ in engs[1:]:
+            e_.close()
 
 
 if __name__ == "__main__":
