@@ -998,9 +998,9 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1w16(CbView cb, int 
 // Grid: (256-sample columns, chunks of groups); thread = sample, a wave = 64 consecutive samples of one group per trip
 // (256 contiguous bytes of wmin; four groups' loads in flight), one list reservation per wave and group.
 __global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t count, int64_t bpad, int64_t chunk,
-                                                   const float *__restrict__ wmin, const uint32_t *__restrict__ gmin1,
+                                                   const float *wmin, const uint32_t *__restrict__ gmin1,
                                                    const float *__restrict__ tau1, uint32_t *__restrict__ cnt,
-                                                   uint16_t *__restrict__ list, float *__restrict__ mark = nullptr) {
+                                                   uint16_t *__restrict__ list, float *mark = nullptr) {
   // mark (= wmin; shard exchange): a (group, sample) pair that is left out gets the value 3.4e38 in place of its level-1
   // minimum -- with a bound from another shard a shard may keep no group at all for a sample, and what is left out must
   // never look like a candidate to the re-rank
@@ -1014,21 +1014,31 @@ __global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t coun
     thr = __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o) + tau1[b];
   }
   const bool live = b < count;                           // (count <= bpad: the loads stay inside the rows of wmin)
-  for (int64_t g0 = g_lo; g0 < g_hi; g0 += 4) {
-    float v[4];
+  // eight groups per trip: their loads in flight together, and ONE vector atomic for the eight list reservations (lane k
+  // reserves for group g0 + k) -- a reservation per group and wave, each waited for in turn, was this kernel's time
+  // (64 round trips per wave: 90 us per 32768 samples whatever the size of the shard)
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int64_t g0 = g_lo; g0 < g_hi; g0 += 8) {
+    float v[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = (live && g0 + k < g_hi) ? wmin[(g0 + k) * bpad + b] : 3.4e38f;
+    for (int k = 0; k < 8; k++) v[k] = (live && g0 + k < g_hi) ? wmin[(g0 + k) * bpad + b] : 3.4e38f;
+    unsigned long long bal[8];
+    uint32_t mine = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const bool in = v[k] <= thr;
-      const unsigned long long bal = __ballot(in);
-      const int64_t g = g0 + k;
-      if (mark && live && g < g_hi && !in) mark[g * bpad + b] = 3.4e38f;
-      if (bal == 0ull) continue;
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&cnt[g], static_cast<uint32_t>(__popcll(bal)));
-      base = __shfl(base, 0, WAVE);
-      if (in) list[g * bpad + base + __popcll(bal & ((1ull << lane) - 1ull))] = static_cast<uint16_t>(b);
+    for (int k = 0; k < 8; k++) {
+      const bool valid = live && g0 + k < g_hi;
+      const bool in = valid && v[k] <= thr;
+      bal[k] = __ballot(in);
+      if (mark && valid && !in) mark[(g0 + k) * bpad + b] = 3.4e38f;
+      if (lane == k) mine = static_cast<uint32_t>(__popcll(bal[k]));
+    }
+    uint32_t base = 0;
+    if (mine) base = atomicAdd(&cnt[g0 + lane], mine);   // (mine != 0 only in lanes 0..7 and only for groups below g_hi)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (bal[k] == 0ull) continue;                      // wave-uniform
+      const uint32_t at = __shfl(base, k, WAVE);
+      if ((bal[k] >> lane) & 1ull) list[(g0 + k) * bpad + at + __popcll(bal[k] & below)] = static_cast<uint16_t>(b);
     }
   }
 }
