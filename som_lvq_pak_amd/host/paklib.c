@@ -1076,7 +1076,8 @@ static int som_training_rank(struct teach_params *teach, int rank, int world, in
       c = (long)(bs + bl - it0);
     }
     if (c != exch_c) {                                 /* every rank has to take the same path: the answers are summed once per batch length */
-      uint32_t f = world > 1 && somhip_shard_exchange_available(cb, ds, c) ? 1u : 0u;
+      /* (the exchange pays from 8 ranks on -- tools/shard_rehearsal.py; SOMHIP_SHARD_EXCHANGE=1 asks for it with fewer) */
+      uint32_t f = (world >= 8 || (world > 1 && getenv("SOMHIP_SHARD_EXCHANGE"))) && somhip_shard_exchange_available(cb, ds, c) ? 1u : 0u;
       if (somhip_copy_to_device(en, dflag, &f, sizeof f) || somhip_comm_allreduce_sum_u32(comm, dflag, 1) ||
           somhip_copy_to_host(en, &f, dflag, sizeof f)) goto hip_fail;
       exch_ok = f == (uint32_t)world;

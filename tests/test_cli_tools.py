@@ -518,8 +518,8 @@ def test_vsom_gpus_flag_equals_one_gpu(tools, tmp_path):
 def test_vsom_gpus_with_exchanged_bounds(tools, tmp_path):
     """vsom -gpus on a shape the two-level pre-filter takes (dim a multiple of 32, batches of 256): the ranks exchange
     the pre-filter's bounds inside every winner search (somhip_shard_winner_begin/refine/finish + the float MIN
-    all-reduce of the C host).  Same bytes as one GPU, and as the ranks without the exchange; the verbose log says
-    which path ran."""
+    all-reduce of the C host; on by itself from 8 ranks on, asked for here with SOMHIP_SHARD_EXCHANGE=1).  Same bytes
+    as one GPU, and as the ranks without the exchange; the verbose log says which path ran."""
     g = "gen:k=10,dim=32,n=6000,seed=21"
     init = tmp_path / "x_init.cod"
     run("randinit", "-din", g, "-cout", init, "-xdim", 24, "-ydim", 24, "-topol", "hexa", "-neigh", "bubble", "-rand", 3, "-v", 0)
@@ -527,7 +527,7 @@ def test_vsom_gpus_with_exchanged_bounds(tools, tmp_path):
     one, two, plain = tmp_path / "x1.cod", tmp_path / "x2.cod", tmp_path / "x2p.cod"
     run("vsom", *common, "-cout", one, "-v", 0)
     p = subprocess.run([os.path.join(BIN, "vsom")] + [str(a) for a in common] + ["-cout", str(two), "-gpus", "3", "-v", "2"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, SOMHIP_SHARD_EXCHANGE="1"))
     assert p.returncode == 0, p.stderr
     assert "bounds exchanged" in p.stderr, p.stderr
     p = subprocess.run([os.path.join(BIN, "vsom")] + [str(a) for a in common] + ["-cout", str(plain), "-gpus", "3", "-v", "2"],

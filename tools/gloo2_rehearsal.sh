@@ -9,7 +9,7 @@ mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 FLAGS="--steps 6 --warmup 1 --cpu-vectors 0 --online-vectors 0 --length 400000 $*"
 python3 bench.py $FLAGS > $OUT/n1.json 2> $OUT/n1.err
-timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
+SOMHIP_SHARD_EXCHANGE=1 timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
     bench.py --gpus 2 --backend gloo $FLAGS > $OUT/n2.json 2> $OUT/n2.err
 SOMHIP_NO_SHARD_EXCHANGE=1 timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29542 \
     bench.py --gpus 2 --backend gloo $FLAGS > $OUT/n2_plain.json 2> $OUT/n2_plain.err
