@@ -1014,18 +1014,19 @@ __global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t coun
     thr = __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o) + tau1[b];
   }
   const bool live = b < count;                           // (count <= bpad: the loads stay inside the rows of wmin)
-  // eight groups per trip: their loads in flight together, and ONE vector atomic for the eight list reservations (lane k
+  // sixteen groups per trip: their loads in flight together, and ONE vector atomic for the sixteen list reservations (lane k
   // reserves for group g0 + k) -- a reservation per group and wave, each waited for in turn, was this kernel's time
   // (64 round trips per wave: 90 us per 32768 samples whatever the size of the shard)
   const unsigned long long below = (1ull << lane) - 1ull;
-  for (int64_t g0 = g_lo; g0 < g_hi; g0 += 8) {
-    float v[8];
+  constexpr int GT = 16;
+  for (int64_t g0 = g_lo; g0 < g_hi; g0 += GT) {
+    float v[GT];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = (live && g0 + k < g_hi) ? wmin[(g0 + k) * bpad + b] : 3.4e38f;
-    unsigned long long bal[8];
+    for (int k = 0; k < GT; k++) v[k] = (live && g0 + k < g_hi) ? wmin[(g0 + k) * bpad + b] : 3.4e38f;
+    unsigned long long bal[GT];
     uint32_t mine = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < GT; k++) {
       const bool valid = live && g0 + k < g_hi;
       const bool in = valid && v[k] <= thr;
       bal[k] = __ballot(in);
@@ -1033,9 +1034,9 @@ __global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t coun
       if (lane == k) mine = static_cast<uint32_t>(__popcll(bal[k]));
     }
     uint32_t base = 0;
-    if (mine) base = atomicAdd(&cnt[g0 + lane], mine);   // (mine != 0 only in lanes 0..7 and only for groups below g_hi)
+    if (mine) base = atomicAdd(&cnt[g0 + lane], mine);   // (mine != 0 only in lanes 0..15 and only for groups below g_hi)
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < GT; k++) {
       if (bal[k] == 0ull) continue;                      // wave-uniform
       const uint32_t at = __shfl(base, k, WAVE);
       if ((bal[k] >> lane) & 1ull) list[(g0 + k) * bpad + at + __popcll(bal[k] & below)] = static_cast<uint16_t>(b);
