@@ -62,10 +62,10 @@ def allreduce_min_keys(keys, group=None, nonnegative=False):
 def allreduce_min_floats(t, group=None):
     """Element-wise MIN of a float32 tensor over all ranks, in place (the exchanged pre-filter bounds)."""
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():                             # (also with one rank: the collective is then a stream-ordered no-op)
         if dist.get_backend(group) == "nccl":
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-        else:
+        elif dist.get_world_size(group) > 1:
             host = t.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
             t.copy_(host)
@@ -179,16 +179,17 @@ class ShardedSom:
             return False
         import torch
         import torch.distributed as dist
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
-            return False                                  # one shard: its own minimum IS the whole codebook's
+        import os
+        asked = os.environ.get("SOMHIP_SHARD_EXCHANGE")
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and asked != "force"):
+            return False                                  # one shard: its own minimum IS the whole codebook's ("force": a 1-rank test of the path)
         # the exchange saves kernel time that grows with the number of shards (tools/shard_rehearsal.py: 33 us per
         # 32768 vectors at 4 shards, 96 at 8) and costs two more small all-reduces: from 8 ranks on, or when asked for
-        import os
-        if dist.get_world_size() < 8 and not os.environ.get("SOMHIP_SHARD_EXCHANGE"):
+        if dist.get_world_size() < 8 and not asked:
             return False
         if count not in self._exch:
             ok = 1 if self.shard.exchange_available(count) else 0
-            if dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.is_initialized():
                 dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
                 t = torch.tensor([ok], dtype=torch.int32, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)

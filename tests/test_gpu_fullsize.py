@@ -131,10 +131,12 @@ def test_c4_online_equals_minibatch_of_one_and_reduced_oracle(world, oracle):
     assert np.array_equal(bits(cbs.download()), bits(oc))
 
 
-def test_rccl_stream_ordered_step_single_rank(oracle):
+@pytest.mark.parametrize("exchange", [False, True])
+def test_rccl_stream_ordered_step_single_rank(oracle, exchange):
     """The production multi-GPU step (scan -> RCCL all-reduce on the engine's own stream via
     torch.cuda.ExternalStream -> update, no host sync) exercised with a 1-rank NCCL group in a
-    child process: must equal the plain mini-batch run."""
+    child process: must equal the plain mini-batch run.  exchange: the step of 8 ranks and more -- the pre-filter's
+    bounds through two float MIN all-reduces inside the winner search (SOMHIP_SHARD_EXCHANGE=force: also with one rank)."""
     import os
     import subprocess
     import sys
@@ -151,7 +153,7 @@ os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 orc = Oracle()
-x, _ = synth(5, 900, 24)
+x, _ = synth(5, 900, %d)
 ini = orc.randinit(x, 16, 16, 3)
 want, wi, _ = orc.som_train(ini, 16, 16, 3, 1, x, 1536, 0.05, 6.0, batch=256)
 eng = E.Engine(0)
@@ -161,12 +163,17 @@ sh = sharded.GpuShard(eng, cb, ds, lambda: SomParams(1536, 0.05, 6.0, 1, 0, 0, 2
 som = sharded.ShardedSom(sh, 256, 900)
 winners = som.train(1536)
 eng.sync(); torch.cuda.synchronize()
+assert bool(som._exch.get(256)) == %r, som._exch
 idx = np.concatenate([sharded.unpack_keys(w.cpu().numpy())[1] for w in winners])
 ok = np.array_equal(idx, wi) and np.array_equal(cb.download().view(np.uint32), want.view(np.uint32))
 dist.destroy_process_group()
 print("RESULT", ok)
-''' % (ROOT, ROOT)
-    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+''' % (ROOT, ROOT, 32 if exchange else 24, exchange)
+    env = dict(os.environ)
+    env.pop("SOMHIP_SHARD_EXCHANGE", None)
+    if exchange:
+        env["SOMHIP_SHARD_EXCHANGE"] = "force"
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
     assert "RESULT True" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
 
 
