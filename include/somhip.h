@@ -266,7 +266,8 @@ int  somhip_som_batch_update(somhip_codebook *cb, somhip_dataset *ds, const somh
  *     host: all-reduce(MIN) of dev_keys, then somhip_som_batch_update
  * After the last all-reduce the keys are bit-identical to those of somhip_batch_winner_keys + all-reduce (the bounds only
  * remove rows that provably cannot win).  The three calls of one search share the engine's scratch memory: nothing else
- * may run on the engine between them.  somhip_shard_exchange_available: 1 if this shape takes the path (bf16 pre-filter,
+ * may run on the engine between them (a call that is not the continuation of the search begun -- out of order, another
+ * codebook, data set or range, a whole search in between -- is refused with an error).  somhip_shard_exchange_available: 1 if this shape takes the path (bf16 pre-filter,
  * dim a multiple of 32, 225 <= count <= 65504, no masks), else 0 -- every rank must take the same path, so a host
  * all-reduces the answer (MIN) once per run. */
 int  somhip_shard_exchange_available(somhip_codebook *cb, somhip_dataset *ds, int64_t count);

@@ -114,6 +114,10 @@ struct somhip_engine {
   double tau_scale = 1.0;                    // >= 1: widen the pre-filter window (experiments only)
   unsigned long long *d_stats = nullptr;     // [4] re-rank statistics (device)
   uint64_t samples_searched = 0;
+  // somhip_shard_winner_begin / _refine / _finish: which search is under way on this engine (0 = none)
+  int xc_phase = 0;
+  const void *xc_cb = nullptr, *xc_ds = nullptr;
+  int64_t xc_first = 0, xc_count = 0;
   uint64_t lvq_batches = 0, lvq_samples = 0;   // exact batched LVQ: rescans and samples
   uint64_t lvq_stop_list = 0, lvq_stop_cache = 0, lvq_cycles[4] = {0, 0, 0, 0};   // batches ended by an exhausted candidate list / a full cache
   int64_t lvq_batch_hint = 256;                   // batch size the exact LVQ engine starts its next call with

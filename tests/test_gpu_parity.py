@@ -382,6 +382,17 @@ def test_shard_winner_search_with_exchanged_bounds(E, oracle):
         assert engs[0].lib.somhip_shard_exchange_available(shards[0].h, dss[0].h, 100) == 0
         kb, bb = engs[0].device_alloc(8 * m), engs[0].device_alloc(4 * m)
         assert engs[0].lib.somhip_shard_winner_begin(small.h, ds40.h, 0, m, kb, bb) != 0
+        # the three calls are one search: out of order, or for another range, they are refused
+        lib0, cb0, ds0 = engs[0].lib, shards[0].h, dss[0].h
+        assert lib0.somhip_shard_winner_refine(cb0, ds0, 0, m, bb) != 0                   # nothing begun
+        assert lib0.somhip_shard_winner_begin(cb0, ds0, 0, m, kb, bb) == 0
+        assert lib0.somhip_shard_winner_finish(cb0, ds0, 0, m, bb, kb) != 0               # refine left out
+        assert lib0.somhip_shard_winner_begin(cb0, ds0, 0, m, kb, bb) == 0
+        assert lib0.somhip_shard_winner_refine(cb0, ds0, 1, m, bb) != 0                   # another range
+        assert lib0.somhip_shard_winner_begin(cb0, ds0, 0, m, kb, bb) == 0
+        assert lib0.somhip_batch_winner_keys(cb0, ds0, 0, m, kb) == 0                     # a whole search in between
+        assert lib0.somhip_shard_winner_refine(cb0, ds0, 0, m, bb) != 0
+        assert b"continuation" in lib0.somhip_last_error()
         engs[0].device_free(kb)
         engs[0].device_free(bb)
     finally:
