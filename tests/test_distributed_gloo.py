@@ -62,6 +62,57 @@ class CheckerShard:
         return contextlib.nullcontext()
 
 
+class CheckerExchangeShard(CheckerShard):
+    """The three-call winner search of sharded.ShardedSom (GpuShard.winner_begin / _refine / _finish in production:
+    somhip_shard_winner_*) on the CPU checker: exact distances stand in for the pre-filter's values, a wide and a narrow
+    slack for its two error bounds.  What is under test is the orchestration: the two float MIN all-reduces, the order
+    of the calls, a shard that abstains."""
+
+    D1, D3 = np.float32(2.0), np.float32(0.05)             # the "error bounds" of the two levels
+
+    def exchange_available(self, count):
+        return True
+
+    def _s(self, first, count):
+        idx = [(first + j) % self.data.shape[0] for j in range(count)]
+        x = self.data[idx]
+        n = self.rows.shape[0]
+        wi, wd, _ = self.orc.winners(self.rows, x, n, True)              # every row's exact distance (find_winner_knn, k = n) ...
+        order = np.argsort((wd.view(np.uint32).astype(np.uint64) << np.uint64(32)) | wi.astype(np.uint64), axis=1)
+        wi, wd = np.take_along_axis(wi, order, 1), np.take_along_axis(wd, order, 1)   # ... in (distance, index) order
+        xx = (x.astype(np.float64) ** 2).sum(1)[:, None]
+        return wi, wd, (wd.astype(np.float64) - xx).astype(np.float32)   # s = distance - ||x||^2, the same on every shard
+
+    def winner_begin(self, first, count):
+        self.wi, self.wd, self.s = self._s(first, count)
+        self.bound = self.torch.from_numpy((self.s[:, 0] + self.D1).copy())
+        self.phase = 1
+        return self.bound
+
+    def winner_refine(self, first, count):
+        assert self.phase == 1
+        ub = self.bound.numpy().copy()                                   # the MIN over the shards
+        assert (ub <= self.s[:, 0] + self.D1).all()
+        self.kept = self.s <= (ub + self.D1)[:, None]                    # rows this shard still has to look at
+        best = np.where(self.kept.any(1), np.where(self.kept, self.s, np.float32(3.4e38)).min(1) + self.D3, np.float32(3.4e38))
+        self.bound.copy_(self.torch.from_numpy(best.astype(np.float32)))
+        self.phase = 2
+        return self.bound
+
+    def winner_finish(self, first, count):
+        from som_lvq_pak_amd.sharded import pack_keys
+        assert self.phase == 2
+        ub = self.bound.numpy()
+        cand = self.kept & (self.s <= (ub + self.D3)[:, None])
+        keys = np.full(count, np.uint64(0x7FFFFFFFFFFFFFFF), dtype=np.uint64)
+        self.abstained = getattr(self, "abstained", 0) + int((~cand.any(1)).sum())
+        for b in np.where(cand.any(1))[0]:
+            j = int(np.argmax(cand[b]))                                  # first candidate in (distance, index) order
+            keys[b] = pack_keys(self.wd[b, j:j + 1], self.units[self.wi[b, j:j + 1]])[0]
+        self.phase = 0
+        return self.torch.from_numpy(keys.view(np.int64).copy())
+
+
 class CheckerLvqShard:
     """topk_keys / merge / candidates / apply of sharded.ShardedLvq for one shard, on the CPU checker.  Serves only ITS
     rows to the exchange; for `apply` (replicated on every rank in production) it keeps a private replica of the whole
@@ -207,6 +258,24 @@ def _worker(rank, world, port, q):
                 want, wi, _ = orc.som_train(ini, xdim, ydim, topol, neigh, x, length, 0.09, 3.0, batch=B)
                 out[case] = (bool(np.array_equal(full.view(np.uint32), want.view(np.uint32))),
                              bool(np.array_equal(widx, wi)))
+        # the winner search with the bounds exchanged between its levels (what 8 ranks and more do; asked for here)
+        os.environ["SOMHIP_SHARD_EXCHANGE"] = "1"
+        x, _ = synth(58, 80, 6)
+        ini = orc.randinit(x, 9, 8, 4)
+        ini[36:] += np.float32(3.0)                          # rank 1's rows lie far off: it abstains for most samples
+        r0, r1 = sharded.shard_rows(72, world, rank)
+        sh = CheckerExchangeShard(orc, ini[r0:r1], np.arange(r0, r1), 72, 9, 3, 1, x, 128, 0.09, 3.0)
+        som = sharded.ShardedSom(sh, 16, x.shape[0])
+        winners = som.train(128)
+        widx = np.concatenate([sharded.unpack_keys(w.numpy())[1] for w in winners])
+        full = sharded.gather_codebook(sh.rows, np.arange(r0, r1), 72)
+        ab = torch.tensor([getattr(sh, "abstained", 0)], dtype=torch.int64)
+        dist.all_reduce(ab)
+        if rank == 0:
+            want, wi, _ = orc.som_train(ini, 9, 8, 3, 1, x, 128, 0.09, 3.0, batch=16)
+            out["exchange"] = (bool(np.array_equal(full.view(np.uint32), want.view(np.uint32))), bool(np.array_equal(widx, wi)),
+                               som._exch.get(16), int(ab.item()) > 0)
+        del os.environ["SOMHIP_SHARD_EXCHANGE"]
         # X2: every rank contributes the k best keys of its shard; the sorted union is the global k-NN
         x, _ = synth(60, 90, 7)
         codes = np.concatenate([x[:50], x[:15]]).astype(np.float32)        # duplicates: knn tie order matters
@@ -261,6 +330,7 @@ def test_sharded_training_world2_gloo():
     assert out[1] == (True, True)
     assert out[2] == (True, True)          # interleaved patches
     assert out["none_key"] == [5, 7]
+    assert out["exchange"] == (True, True, True, True)      # same bits as the unsharded run; the path was taken; a shard abstained
     assert out["knn"] == (True, True)
     for kind in (1, 2, 4):
         assert out["lvq%d" % kind][:3] == (True, True, True), kind
