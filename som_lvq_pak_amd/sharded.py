@@ -139,6 +139,11 @@ def gather_codebook(local_rows, units, n_global, group=None):
     return full
 
 
+def _several_ranks():
+    import torch.distributed as dist
+    return dist.is_initialized() and (dist.get_world_size() > 1 or dist.get_backend() == "nccl")   # (a 1-rank RCCL group: the stream-ordered test)
+
+
 class ShardedSom:
     """Mini-batch SOM training over a row-sharded codebook.
 
@@ -168,8 +173,9 @@ class ShardedSom:
             keys = self.shard.winner_finish(data_first, count)
         else:
             keys = self.shard.winner_keys(data_first, count)
-        with self.shard.collective_scope():
-            allreduce_min_keys(keys, nonnegative=getattr(self.shard, "keys_nonnegative", False))
+        if _several_ranks():                              # (one rank: no collective, so nothing to order it against -- and no host sync)
+            with self.shard.collective_scope():
+                allreduce_min_keys(keys, nonnegative=getattr(self.shard, "keys_nonnegative", False))
         self.shard.update(it0, count, data_first, keys)
         return keys
 
