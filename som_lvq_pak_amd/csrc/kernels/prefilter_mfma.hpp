@@ -1000,7 +1000,9 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1w16(CbView cb, int 
 __global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t count, int64_t bpad, int64_t chunk,
                                                    const float *wmin, const uint32_t *__restrict__ gmin1,
                                                    const float *__restrict__ tau1, uint32_t *__restrict__ cnt,
-                                                   uint16_t *__restrict__ list, float *mark = nullptr) {
+                                                   uint16_t *__restrict__ list, float *mark = nullptr,
+                                                   const float *__restrict__ xub = nullptr) {
+  // xub (shard exchange): the bound agreed between the shards takes the place of this shard's own minimum
   // mark (= wmin; shard exchange): a (group, sample) pair that is left out gets the value 3.4e38 in place of its level-1
   // minimum -- with a bound from another shard a shard may keep no group at all for a sample, and what is left out must
   // never look like a candidate to the re-rank
@@ -1011,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_l2_select(int64_t ngroups, int64_t coun
   float thr = -3.4e38f;
   if (b < count) {
     const uint32_t o = gmin1[b];                         // order-preserving image of the float minimum (float_to_ordered)
-    thr = __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o) + tau1[b];
+    thr = (xub ? xub[b] : __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o)) + tau1[b];
   }
   const bool live = b < count;                           // (count <= bpad: the loads stay inside the rows of wmin)
   // sixteen groups per trip: their loads in flight together, and ONE vector atomic for the sixteen list reservations (lane k

@@ -400,16 +400,6 @@ __global__ void k_shard_bound(int64_t count, const uint32_t *__restrict__ gmin, 
   }
   ub[b] = v;
 }
-// the exchanged bound takes the place of the shard's own minimum (ordered image), the window that of the shard's own
-__global__ void k_shard_apply(int64_t count, const float *__restrict__ ub, uint32_t *__restrict__ gmin,
-                              const float *__restrict__ window, float *__restrict__ win_out) {
-  const int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (b >= count) return;
-  const uint32_t u = __float_as_uint(ub[b]);
-  gmin[b] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // (= float_to_ordered)
-  if (win_out) win_out[b] = window[b];
-}
-
 // K2m: gmin[b] = min over the shard's row groups of the group minima (ordered-uint encoding; the
 // host presets 0xFFFFFFFF).  Workgroup = 32 consecutive samples (one 128-byte line of wmin) x one
 // chunk of groups, 8 interleaved group phases; one atomicMin per (sample, chunk).
@@ -487,7 +477,9 @@ __global__ __launch_bounds__(256) void k_rerank_select(CbView cb, int64_t count,
                                                        uint2 *__restrict__ pairs,
                                                        uint32_t *__restrict__ col_count,
                                                        uint32_t *__restrict__ pair_count,
-                                                       unsigned long long *__restrict__ stats) {
+                                                       unsigned long long *__restrict__ stats,
+                                                       const float *__restrict__ xub = nullptr) {
+  // xub (shard exchange): the bound agreed between the shards takes the place of this shard's own minimum
   // The pair list is cut into one segment of cap_col entries per 32-sample column (blockIdx.x), each
   // with its own counter: a single list counter took ~6 500 same-address atomics per launch and
   // that serialisation, not the 16 MiB of wmin, was this kernel's time.  A full segment raises
@@ -498,7 +490,7 @@ __global__ __launch_bounds__(256) void k_rerank_select(CbView cb, int64_t count,
   const int64_t g_lo = static_cast<int64_t>(blockIdx.y) * chunk;
   const int64_t g_hi = g_lo + chunk < cb.ngroups ? g_lo + chunk : cb.ngroups;
   const bool live = b < count;
-  const float thr = live ? ordered_to_float(gmin[b]) + tau[b] : -3.4e38f;
+  const float thr = live ? (xub ? xub[b] : ordered_to_float(gmin[b])) + tau[b] : -3.4e38f;
   unsigned ngr = 0, nrow = 0;
   uint2 *seg = pairs + static_cast<size_t>(blockIdx.x) * cap_col;
   // blocks of 64 groups (8 per thread): all the loads of a block are issued together and the wave reserves
