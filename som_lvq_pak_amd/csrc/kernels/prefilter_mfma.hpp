@@ -1055,7 +1055,8 @@ __global__ __launch_bounds__(256) void k_dist_l2(CbView cb, int d8, const uint4 
                                                  const float *__restrict__ cn, const float *__restrict__ tau, int64_t bpad,
                                                  const uint32_t *__restrict__ cnt, const uint16_t *__restrict__ list,
                                                  float *__restrict__ wmin, uint64_t *__restrict__ wmask,
-                                                 unsigned long long *__restrict__ stats, const uint4 *__restrict__ xrow = nullptr) {
+                                                 unsigned long long *__restrict__ stats, const uint4 *__restrict__ xrow = nullptr,
+                                                 uint32_t *__restrict__ gmin = nullptr) {
   const int64_t g = blockIdx.x;
   const int n = static_cast<int>(cnt[g]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
@@ -1126,6 +1127,9 @@ __global__ __launch_bounds__(256) void k_dist_l2(CbView cb, int d8, const uint4 
     if (half == 0 && valid) {
       wmin[g * bpad + b] = m;
       wmask[g * bpad + b] = static_cast<uint64_t>(bits) | (static_cast<uint64_t>(other) << 32);
+      // the sample's smallest three-product minimum (what k_group_min would find: a group that level 1 left out keeps a
+      // level-1 value above it, see the window's condition (ii)); ordered image of the float, no value returned
+      if (gmin) { const uint32_t u = __float_as_uint(m); atomicMin(gmin + b, (u & 0x80000000u) ? ~u : (u | 0x80000000u)); }
     }
   }
 }
@@ -1142,7 +1146,8 @@ __global__ __launch_bounds__(64 * L2_WAVES, 1) void k_dist_l2_lds(CbView cb, int
                                                         const float *__restrict__ cn, const float *__restrict__ tau, int64_t bpad,
                                                         const uint32_t *__restrict__ cnt, const uint16_t *__restrict__ list,
                                                         float *__restrict__ wmin, uint64_t *__restrict__ wmask,
-                                                        unsigned long long *__restrict__ stats, const uint4 *__restrict__ xrow = nullptr) {
+                                                        unsigned long long *__restrict__ stats, const uint4 *__restrict__ xrow = nullptr,
+                                                        uint32_t *__restrict__ gmin = nullptr) {
   extern __shared__ uint4 s_l2a[];                         // [hi | lo][d8][64]
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -1232,6 +1237,9 @@ __global__ __launch_bounds__(64 * L2_WAVES, 1) void k_dist_l2_lds(CbView cb, int
     if (half == 0 && valid) {
       wmin[g * bpad + b] = m;
       wmask[g * bpad + b] = static_cast<uint64_t>(bits) | (static_cast<uint64_t>(other) << 32);
+      // the sample's smallest three-product minimum (what k_group_min would find: a group that level 1 left out keeps a
+      // level-1 value above it, see the window's condition (ii)); ordered image of the float, no value returned
+      if (gmin) { const uint32_t u = __float_as_uint(m); atomicMin(gmin + b, (u & 0x80000000u) ? ~u : (u | 0x80000000u)); }
     }
   }
 }
