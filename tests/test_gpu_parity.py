@@ -700,6 +700,28 @@ def test_mfma_prefilter_equals_direct_scan(eng, E, oracle, n, d, m):
         assert np.array_equal(bits(gd), bits(od)), mode
 
 
+@pytest.mark.parametrize("n,d,m,env", [(4096, 64, 512, "SOMHIP_L2_GLOBAL"), (2048, 1024, 300, None),
+                                        (4096, 64, 512, "SOMHIP_NO_FUSED_GMIN"), (4096, 64, 512, None)])
+def test_two_level_level2_variants(eng, E, oracle, monkeypatch, n, d, m, env):
+    """Level 2 of the pre-filter in its two forms -- the group's tiles in LDS (dim <= 512) and operand A from global memory
+    (dim > 512, or SOMHIP_L2_GLOBAL) --, each folding its minima into the per-sample minimum itself, and the separate
+    pass over the matrix (SOMHIP_NO_FUSED_GMIN): the same exact winners."""
+    if env:
+        monkeypatch.setenv(env, "1")
+    x, _ = synth(n + d, m, d)
+    rs = np.random.RandomState(n + d)
+    codes = (x[rs.randint(0, m, n)] + 0.25 * rs.standard_normal((n, d))).astype(np.float32)
+    codes[17] = codes[n - 5] = x[3]                           # an exact tie far apart: the lower index wins
+    cb, ds = E.Codebook(eng, codes), E.Dataset(eng, x)
+    oi, od, _ = oracle.winners(codes, x)
+    before = eng.scan_stats()
+    gi, gd, _ = E.find_winners(cb, ds)
+    after = eng.scan_stats()
+    assert np.array_equal(gi, oi)
+    assert np.array_equal(bits(gd), bits(od))
+    assert after["l2_pairs"] > before["l2_pairs"]             # the two-level form did run
+
+
 def test_mfma_prefilter_adversarial(eng, E, oracle):
     """cases built to break a GEMM-form argmin: exact ties (duplicated rows -> lowest index
     must win), rows one ulp apart, a large common offset (cancellation in ||c||^2 - 2xc),
