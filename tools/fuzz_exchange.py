@@ -37,7 +37,7 @@ def main():
     engs = [E.Engine(0) for _ in range(S_MAX)]
     t0, cases, abstained, samples = time.time(), 0, 0, 0
     while time.time() - t0 < budget:
-        d = int(rs.choice([32, 64, 96, 128, 256, 512]))
+        d = int(rs.choice([32, 64, 96, 128, 256, 512, 1024]))
         m = int(rs.choice([225, 256, 300, 480, 1000, 2049]))
         S = int(rs.randint(2, S_MAX + 1))
         n = int(rs.choice([300, 700, 1500, 5000]))
