@@ -97,10 +97,7 @@ def setup_dist(a):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (a.gpus, a.gpus))
+    if world != a.gpus:                                  # (a bare `--gpus N` never gets here: main() starts the ranks itself)
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU path")
@@ -136,8 +133,40 @@ def pmc_traffic():
     return {}
 
 
+def launcher_command(argv, gpus, port):
+    """The driver's N > 1 command (task contract): one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1;
+    `argv` = this script's own arguments, handed on unchanged."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as a FRESH child (this process has not touched a
+    GPU and never will: no exec of a process that initialised HIP), pass its output through -- rank 0 prints the JSON
+    line -- and leave with its exit code."""
+    cmd = launcher_command(argv, a.gpus, free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print("bench.py: starting %d ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env)
+    try:
+        rc = child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        rc = child.wait()
+    raise SystemExit(rc if rc >= 0 else 128 - rc)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a, sys.argv[1:])
     if a.config != "c4":
         return bench_lvq(a)
     return bench_som(a)

@@ -1008,12 +1008,37 @@ done:
  * socketpair the parent made) -> somhip_som_batch_update of its own rows.  The codebook comes together only at the end
  * (X3), on rank 0, which returns it for saving.  When the ranks outnumber the GPUs (a rehearsal on one GPU: RCCL
  * refuses duplicate devices) or SOMHIP_COMM=sockets, the keys travel over the same sockets instead. */
+#include <errno.h>
+#include <signal.h>
 #include <sys/socket.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
-static int sock_write(int fd, const void *b, size_t n) { const char *p = b; while (n) { ssize_t k = write(fd, p, n); if (k <= 0) return 1; p += k; n -= (size_t)k; } return 0; }
-static int sock_read(int fd, void *b, size_t n) { char *p = b; while (n) { ssize_t k = read(fd, p, n); if (k <= 0) return 1; p += k; n -= (size_t)k; } return 0; }
+/* whole transfers over the ranks' sockets: interrupted calls are repeated; a peer that went away is an error return
+ * (MSG_NOSIGNAL: no SIGPIPE), so that the caller's own clean-up and message are what happens */
+static int sock_write(int fd, const void *b, size_t n)
+{
+  const char *p = b;
+  while (n) {
+    ssize_t k = send(fd, p, n, MSG_NOSIGNAL);
+    if (k < 0 && errno == ENOTSOCK) k = write(fd, p, n);
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) return 1;
+    p += k; n -= (size_t)k;
+  }
+  return 0;
+}
+static int sock_read(int fd, void *b, size_t n)
+{
+  char *p = b;
+  while (n) {
+    ssize_t k = read(fd, p, n);
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) return 1;
+    p += k; n -= (size_t)k;
+  }
+  return 0;
+}
 
 /* what one rank does; fds: rank 0 has world-1 descriptors (peer r at [r-1]), every other rank one (to rank 0) */
 static int som_training_rank(struct teach_params *teach, int rank, int world, int *fds)
@@ -1124,23 +1149,48 @@ done:
   return rc;
 }
 
+/* Ends the ranks still alive: SIGTERM, a grace period, SIGKILL, and reaps every one of them (a rank that sits in a
+ * collective whose peer is gone -- ncclAllReduce / hipStreamSynchronize -- never returns by itself). */
+static void ranks_kill_rest(pid_t *pid, int world)
+{
+  int alive = 0;
+  for (int r = 0; r < world; r++) if (pid[r] > 0) { kill(pid[r], SIGTERM); alive++; }
+  for (int tick = 0; alive && tick < 50; tick++) {           /* up to 5 s */
+    for (int r = 0; r < world; r++)
+      if (pid[r] > 0 && waitpid(pid[r], NULL, WNOHANG) == pid[r]) { pid[r] = 0; alive--; }
+    if (alive) { struct timespec ts = {0, 100000000}; nanosleep(&ts, NULL); }
+  }
+  for (int r = 0; r < world; r++)
+    if (pid[r] > 0) { kill(pid[r], SIGKILL); waitpid(pid[r], NULL, 0); pid[r] = 0; }
+}
+
 /* One process per GPU: forks `world` ranks of the calling process -- which has read its files and has NOT touched a GPU
  * yet -- and runs rank_main(rank, world, fds, arg) in each; fds: rank 0 gets world-1 socket descriptors (peer r at
  * [r-1]), every other rank one (to rank 0).  Rank r uses device r % (visible GPUs) (pak_rank_device).  Returns 0 when
- * every rank returned 0. */
+ * every rank returned 0.  The ranks are reaped in the order in which they end; the first one that fails (non-zero exit
+ * or a signal) -- or a fork() that fails half way -- ends the others (ranks_kill_rest) and the call returns 1: no rank
+ * is left behind in a collective, no orphan keeps a GPU.  Children are only ever started fresh or killed, never
+ * re-executed. */
 int pak_run_ranks(int world, int (*rank_main)(int rank, int world, int *fds, void *arg), void *arg)
 {
   if (g_engine) { fprintf(stderr, "the ranks must be started before this process uses a GPU\n"); return 1; }
   if (world < 1 || world > 64) { fprintf(stderr, "-gpus %d?\n", world); return 1; }
   int (*sv)[2] = malloc(sizeof(int[2]) * (world > 1 ? world - 1 : 1));
   for (int r = 1; r < world; r++)
-    if (socketpair(AF_UNIX, SOCK_STREAM, 0, sv[r - 1])) { perror("socketpair"); free(sv); return 1; }
-  pid_t *pid = malloc(sizeof(pid_t) * world);
+    if (socketpair(AF_UNIX, SOCK_STREAM, 0, sv[r - 1])) {
+      perror("socketpair");
+      for (int q = 1; q < r; q++) { close(sv[q - 1][0]); close(sv[q - 1][1]); }
+      free(sv);
+      return 1;
+    }
+  pid_t *pid = calloc((size_t)world, sizeof(pid_t));
   fflush(NULL);
-  for (int r = 0; r < world; r++) {
+  int bad = 0;
+  for (int r = 0; r < world && !bad; r++) {
     pid[r] = fork();
-    if (pid[r] < 0) { perror("fork"); free(sv); free(pid); return 1; }
+    if (pid[r] < 0) { perror("fork"); pid[r] = 0; bad = 1; break; }
     if (pid[r] == 0) {
+      signal(SIGPIPE, SIG_IGN);      /* a peer that went away is an error return of the write (host_comm.inc), not a signal */
       int *fds = malloc(sizeof(int) * (world > 1 ? world - 1 : 1));
       for (int q = 1; q < world; q++) {
         if (r == 0) { fds[q - 1] = sv[q - 1][0]; close(sv[q - 1][1]); }
@@ -1154,11 +1204,23 @@ int pak_run_ranks(int world, int (*rank_main)(int rank, int world, int *fds, voi
     }
   }
   for (int r = 1; r < world; r++) { close(sv[r - 1][0]); close(sv[r - 1][1]); }
-  int bad = 0;
-  for (int r = 0; r < world; r++) {
+  int left = 0;
+  for (int r = 0; r < world; r++) if (pid[r] > 0) left++;
+  while (!bad && left > 0) {
     int st = 0;
-    if (waitpid(pid[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+    const pid_t w = waitpid(-1, &st, 0);
+    if (w < 0) { if (errno == EINTR) continue; bad = 1; break; }
+    int r = 0;
+    while (r < world && pid[r] != w) r++;
+    if (r == world) continue;                                  /* some other child of the host program */
+    pid[r] = 0; left--;
+    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+      if (WIFSIGNALED(st)) fprintf(stderr, "rank %d ended by signal %d; stopping the other ranks\n", r, WTERMSIG(st));
+      else fprintf(stderr, "rank %d failed; stopping the other ranks\n", r);
+      bad = 1;
+    }
   }
+  if (bad) ranks_kill_rest(pid, world);
   free(sv); free(pid);
   return bad;
 }

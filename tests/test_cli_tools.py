@@ -78,6 +78,24 @@ def test_registry_row_dist_and_adapt_equal_the_oracle(tools, tmp_path):
     assert p.returncode == 0 and p.stdout.strip().endswith("mismatches 0"), p.stdout
 
 
+def test_a_failing_rank_ends_the_others(tools, tmp_path):
+    """pak_run_ranks (paklib.c; `vsom/lvqtrain/vfind -gpus G`): a rank that exits non-zero or dies of a signal while
+    the others block (rank 0 in a read from a live peer, the rest in pause() -- as a rank inside an RCCL collective
+    would) ends them all: the call returns 1 within seconds and no child is left"""
+    exe = str(tmp_path / "ranks_fail")
+    host = os.path.join(ROOT, "som_lvq_pak_amd", "host")
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-I", host, "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "helpers", "ranks_fail.c"), os.path.join(host, "paklib.c"),
+                           "-L", os.path.join(ROOT, "som_lvq_pak_amd"), "-lsomhip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "som_lvq_pak_amd"), "-lm"])
+    for mode, world, want in (("ok", 4, 0), ("exit", 3, 1), ("signal", 4, 1), ("exit", 2, 1)):
+        p = subprocess.run([exe, mode, str(world)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+        assert p.returncode == 0, p.stderr
+        assert p.stdout.startswith("returned %d after" % want) and p.stdout.strip().endswith("children left 0"), (mode, p.stdout, p.stderr)
+        secs = float(p.stdout.split("after")[1].split("s;")[0])
+        assert secs < 10.0, p.stdout
+
+
 def test_tools_refuse_without_gpu(tools, tmp_path):
     import torch
     if torch.cuda.is_available():
