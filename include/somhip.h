@@ -163,9 +163,9 @@ int  somhip_find_winners(somhip_codebook *cb, somhip_dataset *ds, int64_t first,
  *             neighbourhood updates are applied in iteration order (exact oracle:
  *             orc_som_training(batch) in oracle/).
  * batch == SOMHIP_BATCH_AUTO: the mini-batch schedule with the engine's own batch sizes (somhip_som_auto_batch):
- *             long batches while the map is still being ordered, shorter ones over the last quarter of the
- *             schedule, where the final state is decided -- measured at configs[3]'s real length
- *             (profiles/r02_batch_schedule_study.txt): final qerror within 1e-5 of the online result.
+ *             long batches while the end state still forgets them, short ones after -- or batch 1 where that rule
+ *             has not been measured against the online engine (small maps, short runs).  Measured at configs[3]'s
+ *             real length on three seed pairs (profiles/r03_conformity_*.jsonl).
  * trace_index/trace_diff (host, [count], may be NULL): winner of every iteration;
  * -2 = skipped (sample fully masked), -3 = fixed-point sample (no search). */
 #define SOMHIP_BATCH_AUTO (-1)
@@ -181,12 +181,19 @@ typedef struct somhip_som_params {
 } somhip_som_params;
 int  somhip_som_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_params *p,
                       int32_t *trace_index, float *trace_diff);
-/* The batch of the SOMHIP_BATCH_AUTO schedule that holds iteration `iter` of a schedule of `length` iterations:
- * [*batch_start, *batch_start + *batch_len).  32768 iterations per batch over the first three quarters of the
- * schedule (rounded down to whole batches), 8192 after; schedules shorter than 32 long batches: 4096 throughout.
+/* The batch of the SOMHIP_BATCH_AUTO schedule that holds iteration `iter`: [*batch_start, *batch_start + *batch_len).
+ * p: length, alpha, alpha_type, radius of the run (teach_params, lvq_pak.h:186-204); n_units = xdim * ydim of the WHOLE map
+ * (also on a shard), topol / neigh as in the codebook.  The schedule is a rule in (n_units, radius(t), alpha(t)) --
+ * csrc/host_som.inc, som_auto_plan: 32768 iterations per batch while what a batch leaves in the map is forgotten again by
+ * the end of the run (the sum of alpha(t') x the share of the map one sample teaches over the rest of the run is >= 12),
+ * after that the largest power of two that moves no unit more than a quarter of the way to its samples within one batch
+ * (configs[3]: 32768 up to iteration 9 011 200 of 10 M, then 4096).  Where the rule is not vouched for by a measurement
+ * against the online engine -- maps below 16384 units, runs whose long phase holds fewer than 64 long batches -- every
+ * batch is ONE iteration: `auto` is then the reference's own online schedule (bit-exact).
  * A host that drives somhip_batch_winner_keys / somhip_som_batch_update itself (one process per GPU) asks this
- * function for its batch boundaries, so that every rank cuts the run the same way. */
-int  somhip_som_auto_batch(int64_t length, int64_t iter, int64_t *batch_start, int64_t *batch_len);
+ * function for its batch boundaries, so that every rank cuts the run the same way.  Plain host arithmetic: no GPU needed. */
+int  somhip_som_auto_batch(const somhip_som_params *p, int64_t n_units, int topol, int neigh, int64_t iter,
+                           int64_t *batch_start, int64_t *batch_len);
 
 /* ---- lvq1/olvq1/lvq2/lvq3_training (lvq_rout.c:498,584,702,808) --------------
  * kind = SOMHIP_LVQ1..LVQ3.  talpha (host, [n_rows], in/out) = OLVQ1's per-code

@@ -69,7 +69,8 @@ SIGNATURES = {
     "somhip_find_winners": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                       c_i32_p, c_float_p, c_i32_p]),
     "somhip_som_train": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SomParams), c_i32_p, c_float_p]),
-    "somhip_som_auto_batch": (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "somhip_som_auto_batch": (C.c_int, [C.POINTER(SomParams), C.c_int64, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int64)]),
     "somhip_lvq_train": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(LvqParams), c_float_p, c_i32_p,
                                    c_float_p]),
     "somhip_batch_winner_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),

@@ -28,6 +28,7 @@
 #include "kernels/som_update_gemm.hpp"
 #include "kernels/som_online.hpp"
 #include "kernels/rerank.hpp"
+#include "kernels/prefilter_l1_ring.hpp"
 #include "kernels/lvq.hpp"
 #include "kernels/lvq_batch.hpp"
 #include "kernels/qerror2_lininit.hpp"

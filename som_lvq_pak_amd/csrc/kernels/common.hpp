@@ -178,9 +178,15 @@ __device__ __forceinline__ float gaussian_alpha(float lat_sq, float radius, floa
 struct StepScalars {
   float alpha;     // talp after schedule (+ weights), som_rout.c:617-624
   float thresh;    // bubble: largest lattice_sq value still inside the radius; gaussian: trad
-  int32_t fixed;   // >= 0: unit index from the sample's fixed point (som_rout.c:628-632)
+  int32_t fixed;   // >= 0: the sample's fixed point (som_rout.c:628-632) as (yfix << 15) | xfix -- lattice
+                   // coordinates, not a unit: the reference hands them to the neighbourhood function as they are,
+                   // so a point beyond the map's edge teaches the units within the radius of it
   int32_t reach;   // >= 0: how many lattice rows the neighbourhood can span (conservative);
                    // -1: every component masked -> no search, no update (som_rout.c:635-640)
 };
+
+__host__ __device__ __forceinline__ int32_t fixed_pack(int fx, int fy) { return (fy << 15) | fx; }   // 0 <= fx, fy < 32768
+__host__ __device__ __forceinline__ int fixed_x(int32_t f) { return f & 32767; }
+__host__ __device__ __forceinline__ int fixed_y(int32_t f) { return f >> 15; }
 
 }  // namespace somhip

@@ -114,18 +114,20 @@ __global__ __launch_bounds__(256) void k_som_online_step(CbView cb, const float 
   float a = 0.0f;
   if (has_prev) {
     const StepScalars s = *prev_sc;
-    uint32_t widx = 0xFFFFFFFFu;
+    int bx = -1, by = -1;
     if (s.reach >= 0) {
-      if (s.fixed >= 0) widx = static_cast<uint32_t>(s.fixed);
+      if (s.fixed >= 0) { bx = fixed_x(s.fixed); by = fixed_y(s.fixed); }
       else {
         uint64_t k = *prev_slot;
-        if (static_cast<uint32_t>(k >> 32) < FLT_MAX_BITS) widx = static_cast<uint32_t>(k);
+        if (static_cast<uint32_t>(k >> 32) < FLT_MAX_BITS) {
+          const uint32_t widx = static_cast<uint32_t>(k);
+          bx = static_cast<int>(widx % xdim); by = static_cast<int>(widx / xdim);
+        }
       }
     }
-    if (widx != 0xFFFFFFFFu) {
+    if (bx >= 0) {
       int tx, ty;
       txty_of_row(cb, row, tx, ty);
-      const int bx = static_cast<int>(widx % xdim), by = static_cast<int>(widx / xdim);
       const float lsq = lattice_sq(cb.topol, bx, by, tx, ty);
       if (GAUSS) { a = gaussian_alpha(lsq, s.thresh, s.alpha); upd = live; }
       else { a = s.alpha; upd = live && (lsq <= s.thresh); }

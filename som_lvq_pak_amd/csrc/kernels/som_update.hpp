@@ -18,14 +18,14 @@ __global__ void k_decode_winners(const uint64_t *__restrict__ keys, const StepSc
   const StepScalars s = sc[b];
   int2 o = make_int2(-1, -1);
   if (s.reach >= 0) {
-    uint32_t widx = 0xFFFFFFFFu;
-    if (s.fixed >= 0) widx = static_cast<uint32_t>(s.fixed);
+    if (s.fixed >= 0) o = make_int2(fixed_x(s.fixed), fixed_y(s.fixed));
     else {
       uint64_t k = keys[b];
-      if (static_cast<uint32_t>(k >> 32) < FLT_MAX_BITS) widx = static_cast<uint32_t>(k);
+      if (static_cast<uint32_t>(k >> 32) < FLT_MAX_BITS) {
+        const uint32_t widx = static_cast<uint32_t>(k);
+        o = make_int2(static_cast<int>(widx % static_cast<uint32_t>(xdim)), static_cast<int>(widx / static_cast<uint32_t>(xdim)));
+      }
     }
-    if (widx != 0xFFFFFFFFu) o = make_int2(static_cast<int>(widx % static_cast<uint32_t>(xdim)),
-                                           static_cast<int>(widx / static_cast<uint32_t>(xdim)));
   }
   bxy[b] = o;
 }
@@ -112,10 +112,14 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
       if (keys) {                                        // winners decoded here (K4a's rule), no extra launch
         w = make_int2(-1, -1);
         if (s.reach >= 0) {
-          uint32_t widx = 0xFFFFFFFFu;
-          if (s.fixed >= 0) widx = static_cast<uint32_t>(s.fixed);
-          else { const uint64_t k = keys[b]; if (static_cast<uint32_t>(k >> 32) < FLT_MAX_BITS) widx = static_cast<uint32_t>(k); }
-          if (widx != 0xFFFFFFFFu) w = make_int2(static_cast<int>(widx % xdim), static_cast<int>(widx / xdim));
+          if (s.fixed >= 0) w = make_int2(fixed_x(s.fixed), fixed_y(s.fixed));
+          else {
+            const uint64_t k = keys[b];
+            if (static_cast<uint32_t>(k >> 32) < FLT_MAX_BITS) {
+              const uint32_t widx = static_cast<uint32_t>(k);
+              w = make_int2(static_cast<int>(widx % xdim), static_cast<int>(widx / xdim));
+            }
+          }
         }
       } else {
         w = bxy[b];

@@ -143,6 +143,8 @@ struct somhip_engine {
   std::vector<somhip_dataset *> datasets;
   bool lvq_apply_attr_set = false;             // hipFuncSetAttribute(k_lvq_batch_apply, ...) done on this device
   bool l2_lds_attr_set = false;                // ... and for k_dist_l2_lds
+  bool l1r_attr_set = false;                   // ... and for k_dist_mfma_bf16_l1r
+  int n_cus = 0;                               // compute units of the device (grid of the persistent kernels)
   LvqCtl *lvq_hctl = nullptr;                  // pinned: read-backs of the LVQ batch loop's control block, one per batch in flight
   hipEvent_t lvq_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };

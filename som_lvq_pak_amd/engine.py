@@ -326,10 +326,14 @@ def som_train(cb, ds, length, alpha, radius, alpha_type=ALPHA_LINEAR, use_fixed=
 BATCH_AUTO = -1          # somhip.h SOMHIP_BATCH_AUTO: the engine's own mini-batch sizes along the schedule
 
 
-def som_auto_batch(lib, length, it):
-    """(start, length) of the SOMHIP_BATCH_AUTO batch that holds iteration `it` (somhip_som_auto_batch)"""
+def som_auto_batch(lib, length, it, alpha=0.05, radius=128.0, n_units=65536, topol=TOPOL_HEXA, neigh=NEIGH_BUBBLE,
+                   alpha_type=ALPHA_LINEAR):
+    """(start, length) of the SOMHIP_BATCH_AUTO batch that holds iteration `it` of a run of `length` iterations with these
+    parameters on a map of n_units units (somhip_som_auto_batch: a rule in (units, radius(t), alpha(t)); (it, 1) where the
+    rule does not vouch for mini-batches); defaults = configs[3]"""
     a, b = C.c_int64(0), C.c_int64(0)
-    check(lib.somhip_som_auto_batch(length, it, C.byref(a), C.byref(b)))
+    p = SomParams(length, alpha, radius, alpha_type, 0, 0, BATCH_AUTO, 0, 0, 0)
+    check(lib.somhip_som_auto_batch(C.byref(p), n_units, topol, neigh, it, C.byref(a), C.byref(b)))
     return a.value, b.value
 
 

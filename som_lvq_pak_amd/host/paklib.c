@@ -1097,7 +1097,7 @@ static int som_training_rank(struct teach_params *teach, int rank, int world, in
     const long first = it0 % data->num_entries;
     if (auto_b) {
       int64_t bs, bl;
-      if (somhip_som_auto_batch(L, it0, &bs, &bl)) goto hip_fail;
+      if (somhip_som_auto_batch(&sp, n, codes->topol, codes->neigh, it0, &bs, &bl)) goto hip_fail;
       c = (long)(bs + bl - it0);
     }
     if (c != exch_c) {                                 /* every rank has to take the same path: the answers are summed once per batch length */

@@ -33,30 +33,48 @@ def test_header_symbols_exported(built):
 
 def test_auto_batch_schedule_is_host_arithmetic(built):
     """somhip_som_auto_batch (the engine's own mini-batch boundaries, SOMHIP_BATCH_AUTO) is plain host arithmetic: it must
-    answer without a GPU, cut a schedule into contiguous batches that end exactly at its length, and refuse nonsense."""
+    answer without a GPU, cut a schedule into contiguous batches that end exactly at its length, follow its rule in
+    (units, radius(t), alpha(t)) -- long batches while the rest of the run still forgets them, a short power of two after,
+    batch 1 wherever the rule is not vouched for -- and refuse nonsense."""
     import ctypes as C
     from som_lvq_pak_amd import _lib
     lib = _lib.load()
 
-    def ab(length, it):
+    def ab(length, it, alpha=0.05, radius=128.0, units=65536, topol=3, neigh=1, alpha_type=1):
         a, b = C.c_int64(0), C.c_int64(0)
-        rc = lib.somhip_som_auto_batch(length, it, C.byref(a), C.byref(b))
+        p = _lib.SomParams(length, alpha, radius, alpha_type, 0, 0, -1, 0, 0, 0)
+        rc = lib.somhip_som_auto_batch(C.byref(p), units, topol, neigh, it, C.byref(a), C.byref(b))
         return rc, a.value, b.value
 
-    for length in (1, 4095, 100000, 32 * 32768, 10_000_000):
+    def cut(length, **kw):
         it, sizes = 0, []
         while it < length:
-            rc, st, ln = ab(length, it)
+            rc, st, ln = ab(length, it, **kw)
             assert rc == 0 and st == it and 0 < ln <= 32768 and st + ln <= length
-            assert ab(length, st + ln - 1)[1:] == (st, ln)          # every iteration of the batch names the same batch
+            assert ab(length, st + ln - 1, **kw)[1:] == (st, ln)    # every iteration of the batch names the same batch
             sizes.append(ln)
             it = st + ln
         assert it == length
-        if length >= 32 * 32768:                                    # long batches first, short ones over the last quarter
-            assert sizes[0] == 32768 and sizes[-2] == 8192 and sorted(sizes[:-1], reverse=True) == sizes[:-1]
-        else:
-            assert max(sizes) <= 4096
-    assert ab(1000, 1000)[0] != 0 and ab(0, 0)[0] != 0 and ab(1000, -1)[0] != 0
+        return sizes
+
+    # configs[3]: 256 x 256 hexa bubble, alpha 0.05 linear, radius 128 -> 1, 10 M iterations
+    sizes = cut(10_000_000)
+    nlong = sizes.index(4096)
+    assert sizes[:nlong] == [32768] * nlong and set(sizes[nlong:-1]) == {4096} and sizes[-1] <= 4096
+    assert 0.88 < nlong * 32768 / 1e7 < 0.92                       # the long batches end where exp(-F) = e^-12 is left of them
+    # the rule follows its inputs: a larger rate or a gaussian neighbourhood forgets faster (long batches run on longer),
+    # more units per sample's neighbourhood move less per batch (longer tail batches)
+    assert cut(10_000_000, alpha=0.2).index(cut(10_000_000, alpha=0.2)[-2]) > nlong
+    assert cut(10_000_000, neigh=2).count(32768) > nlong
+    big = cut(40_000_000, units=262144, radius=256.0)
+    assert big[0] == 32768 and big[-2] in (8192, 16384)
+    assert cut(10_000_000, alpha_type=2)[0] in (1, 32768)           # inverse_t: still a valid cut
+    # not vouched for -> the reference's own schedule: small maps (configs[1]), short runs, runs too short for 64 long batches
+    for length, kw in ((100000, dict(radius=10.0, units=1024)), (1, {}), (4095, {}), (32 * 32768, {}), (10_000_000, dict(units=16383)),
+                       (10_000_000, dict(alpha=0.0)), (70 * 32768, {})):
+        for it in (0, length // 2, length - 1):
+            assert ab(length, it, **kw) == (0, it, 1), (length, kw)
+    assert ab(1000, 1000)[0] != 0 and ab(0, 0)[0] != 0 and ab(1000, -1)[0] != 0 and ab(1000, 5, units=0)[0] != 0
 
 
 def test_no_cpu_fallback(built):

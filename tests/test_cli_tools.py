@@ -557,20 +557,28 @@ def test_vsom_gpus_with_exchanged_bounds(tools, tmp_path):
 
 @pytest.mark.gpu
 def test_vsom_batch_auto(tools, tmp_path):
-    """vsom -batch auto: the engine's own batch boundaries (somhip_som_auto_batch) -- the bytes of the same run made in
-    two explicit segments' worth of fixed batches are not reachable from the command line, so: one GPU == three ranks
-    (every rank asks the library for the same boundaries), and != a fixed -batch 4096 run (the schedule really differs)."""
+    """vsom -batch auto: the engine's own batch boundaries (somhip_som_auto_batch, a rule in (units, radius, alpha)).  On a
+    map the rule vouches for (128 x 128, 80 long batches and more): one GPU == three ranks (every rank asks the library for
+    the same boundaries), and != a fixed -batch 4096 run (the schedule really differs).  On a small map `auto` is the
+    reference's own online schedule: the bytes of -batch 1 (= no -batch flag at all)."""
     g = "gen:k=6,dim=8,n=20000,seed=5"
     init = tmp_path / "a_init.cod"
-    run("randinit", "-din", g, "-cout", init, "-xdim", 16, "-ydim", 16, "-topol", "hexa", "-neigh", "bubble", "-rand", 4, "-v", 0)
-    L = 32 * 32768 + 5000
-    common = ["-din", g, "-cin", init, "-rlen", L, "-alpha", 0.05, "-radius", 8, "-v", 0]
+    run("randinit", "-din", g, "-cout", init, "-xdim", 128, "-ydim", 128, "-topol", "hexa", "-neigh", "bubble", "-rand", 4, "-v", 0)
+    L = 80 * 32768 + 5000
+    common = ["-din", g, "-cin", init, "-rlen", L, "-alpha", 0.05, "-radius", 64, "-v", 0]
     a, b, c = tmp_path / "auto1.cod", tmp_path / "auto3.cod", tmp_path / "fixed.cod"
     run("vsom", *common, "-batch", "auto", "-cout", a)
     run("vsom", *common, "-batch", "auto", "-cout", b, "-gpus", 3)
     run("vsom", *common, "-batch", 4096, "-cout", c)
     assert md5(a) == md5(b)
     assert md5(a) != md5(c)
+    small = tmp_path / "s_init.cod"
+    run("randinit", "-din", g, "-cout", small, "-xdim", 16, "-ydim", 16, "-topol", "hexa", "-neigh", "bubble", "-rand", 4, "-v", 0)
+    common = ["-din", g, "-cin", small, "-rlen", 30000, "-alpha", 0.05, "-radius", 8, "-v", 0]
+    d, e = tmp_path / "s_auto.cod", tmp_path / "s_online.cod"
+    run("vsom", *common, "-batch", "auto", "-cout", d)
+    run("vsom", *common, "-cout", e)
+    assert md5(d) == md5(e)
 
 
 @pytest.mark.gpu

@@ -511,29 +511,44 @@ def test_top8_two_level_and_by_group_equal_the_plain_paths(eng, E, oracle):
 
 
 def test_engine_chosen_batch_schedule_is_the_documented_one(eng, E):
-    """SOMHIP_BATCH_AUTO: 32768-iteration batches over the first three quarters of the schedule (whole batches), 8192 after;
-    short schedules 4096 -- and a run with it equals the same run made in two explicit segments, bit for bit."""
+    """SOMHIP_BATCH_AUTO (somhip_som_auto_batch): at configs[3]'s parameters 32768-iteration batches up to iteration
+    9 011 200 (whole batches), 4096 after; a map the rule does not vouch for: batch 1.  A run with it equals the same run
+    made in two explicit segments (maps it vouches for) or the online engine's (small maps), bit for bit."""
     lib = eng.lib
     BL = 32768
-    L = 32 * BL
-    t1 = (3 * (L // 4)) // BL * BL
-    assert E.som_auto_batch(lib, L, 0) == (0, BL)
-    assert E.som_auto_batch(lib, L, t1 - 1) == (t1 - BL, BL)
-    assert E.som_auto_batch(lib, L, t1) == (t1, 8192)
-    assert E.som_auto_batch(lib, L, L - 1) == (L - 8192, 8192)
-    t10 = (3 * (10_000_000 // 4)) // BL * BL
-    last = t10 + (9_999_999 - t10) // 8192 * 8192
-    assert E.som_auto_batch(lib, 10_000_000, 9_999_999) == (last, 10_000_000 - last)
-    assert E.som_auto_batch(lib, 100000, 5000) == (4096, 4096)
+    L10 = 10_000_000
+    t10 = 275 * BL
+    assert E.som_auto_batch(lib, L10, 0) == (0, BL)
+    assert E.som_auto_batch(lib, L10, t10 - 1) == (t10 - BL, BL)
+    assert E.som_auto_batch(lib, L10, t10) == (t10, 4096)
+    last = t10 + (L10 - 1 - t10) // 4096 * 4096
+    assert E.som_auto_batch(lib, L10, L10 - 1) == (last, L10 - last)
+    assert E.som_auto_batch(lib, 100000, 5000, radius=10.0, n_units=1024) == (5000, 1)
+    # 128 x 128 map, 100 long batches' worth of iterations over a 4096-vector data set
     x, _ = synth(31, 4096, 16, k=5, spread=2.0)
     rs = np.random.RandomState(3)
-    init = (x[rs.randint(0, 4096, 256)] + 0.1 * rs.standard_normal((256, 16))).astype(np.float32)
+    n = 128 * 128
+    init = (x[rs.randint(0, 4096, n)] + 0.1 * rs.standard_normal((n, 16))).astype(np.float32)
+    L = 100 * BL
+    kw = dict(alpha=0.05, radius=64.0, n_units=n)
+    t1 = next(t for t in range(0, L, BL) if E.som_auto_batch(lib, L, t, **kw)[1] != BL)
+    bt = E.som_auto_batch(lib, L, t1, **kw)[1]
+    assert t1 >= 64 * BL and bt < BL and E.som_auto_batch(lib, L, L - 1, **kw)[1] <= bt
     ds = E.Dataset(eng, x)
+    a = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, 128, 128)
+    E.som_train(a, ds, L, 0.05, 64.0, batch=E.BATCH_AUTO, trace=False)
+    b = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, 128, 128)
+    E.som_train(b, ds, L, 0.05, 64.0, batch=BL, count=t1, trace=False)
+    E.som_train(b, ds, L, 0.05, 64.0, batch=bt, start_iter=t1, trace=False)
+    assert np.array_equal(bits(a.download()), bits(b.download()))
+    a.close(); b.close()
+    # a small map: auto == online, traces included
+    init = init[:256]
     a = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, 16, 16)
-    E.som_train(a, ds, L, 0.05, 8.0, batch=E.BATCH_AUTO, trace=False)
+    ta = E.som_train(a, ds, 6000, 0.05, 8.0, batch=E.BATCH_AUTO)
     b = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, 16, 16)
-    E.som_train(b, ds, L, 0.05, 8.0, batch=BL, count=t1, trace=False)
-    E.som_train(b, ds, L, 0.05, 8.0, batch=8192, start_iter=t1, trace=False)
+    tb = E.som_train(b, ds, 6000, 0.05, 8.0, batch=1)
+    assert np.array_equal(ta[0], tb[0]) and np.array_equal(bits(ta[1]), bits(tb[1]))
     assert np.array_equal(bits(a.download()), bits(b.download()))
 
 
@@ -849,6 +864,30 @@ def test_patch_row_order_equals_oracle(eng, E, oracle, topol, neigh, batch):
     wi, wd, _ = E.find_winners(cb, ds)
     qi, qd, _ = oracle.winners(oc, x)
     assert np.array_equal(wi, qi) and np.array_equal(bits(wd), bits(qd))
+
+
+@pytest.mark.parametrize("neigh", [1, 2])
+def test_fixed_points_beyond_the_edge_of_the_map(eng, E, oracle, neigh):
+    """som_rout.c:628-632 hands xfix / yfix to the neighbourhood function as they are: a fixed point beyond the map's
+    edge teaches the units within the radius of it (the engine used to refuse such a data file in the
+    middle of training).  Online and mini-batch, 8x8-patch and linear row order, against the oracle's bits."""
+    rs = np.random.RandomState(17)
+    x, _ = synth(82, 400, 12)
+    fixed = np.full((400, 2), -1, dtype=np.int16)
+    for r in rs.choice(400, 40, replace=False):
+        fixed[r] = (rs.randint(0, 30), rs.randint(0, 26))           # map is 16 x 8 (and 13 x 9): most of these lie outside
+    fixed[5] = (16, 3); fixed[6] = (3, 8); fixed[7] = (200, 300); fixed[8] = (32767, 32767)
+    for xd, yd in ((16, 8), (13, 9)):
+        ini = oracle.randinit(x, xd, yd, 4)
+        for batch in (1, 48):
+            oc, oi, od = oracle.som_train(ini, xd, yd, 3, neigh, x, 700, 0.07, 5.0, fixed_xy=fixed, fixed_on=1, batch=batch)
+            cb = E.Codebook(eng, ini, 3, neigh, xd, yd)
+            ds = E.Dataset(eng, x, fixed_xy=fixed)
+            ti, td = E.som_train(cb, ds, 700, 0.07, 5.0, use_fixed=1, batch=batch)
+            assert np.array_equal(ti, oi), (xd, batch)
+            assert np.array_equal(bits(td), bits(od)), (xd, batch)
+            assert np.array_equal(bits(cb.download()), bits(oc)), (xd, batch)
+            cb.close(); ds.close()
 
 
 def test_patch_row_order_masks_fixed_weights_and_shards(eng, E, oracle):

@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--online-from", default=None, help=".npz of an earlier call's online result (skips the online run)")
     ap.add_argument("--save-online", default=None)
     ap.add_argument("--no-online", action="store_true")
+    ap.add_argument("--perturb-init", action="store_true",
+                    help="control: the live online run starts from the initial map with ONE component moved by one ulp "
+                         "(use with --online-from: the unperturbed online result is then the reference of the deltas)")
     ap.add_argument("--out", default="gpurun_out/conformity_r3.jsonl")
     a = ap.parse_args()
     L, xdim, ydim, d = a.length, a.xdim, a.ydim, a.dim
@@ -97,7 +100,27 @@ def main():
         return m, r
 
     online = None
-    if a.online_from:
+    if a.perturb_init:                                   # the reference's own algorithm, one last bit of its input changed
+        base = None
+        if a.online_from:
+            z = np.load(a.online_from)
+            r = np.sqrt(z["diff"].astype(np.float64))
+            base = {"r": r, "qerror_f32": float(f32_sum(r[:ne]) / np.float32(ne)), "mean_f64": float(r[:ne].mean()),
+                    "mean_f64_wide": float(r[:nw].mean())}
+        pin = init.copy()
+        pin[0, 0] = np.nextafter(pin[0, 0], np.float32(np.inf))
+        cb.upload(pin)
+        eng.sync()
+        t0 = time.perf_counter()
+        seg = 1 << 18
+        for s in range(0, L, seg):
+            p = SomParams(L, a.alpha, radius, E.ALPHA_LINEAR, 0, 0, 1, s, min(seg, L - s), s)
+            E.check(eng.lib.somhip_som_train(cb.h, ds.h, __import__("ctypes").byref(p), None, None))
+            print("online (perturbed init) %d / %d (%.0f s)" % (min(s + seg, L), L, time.perf_counter() - t0), file=sys.stderr, flush=True)
+        eng.sync()
+        measures("online, init[0][0] + 1 ulp", time.perf_counter() - t0, base)
+        online = base
+    elif a.online_from:
         z = np.load(a.online_from)
         r = np.sqrt(z["diff"].astype(np.float64))
         online = {"r": r, "qerror_f32": float(f32_sum(r[:ne]) / np.float32(ne)), "mean_f64": float(r[:ne].mean()),
