@@ -10,7 +10,7 @@ alpha 0.05 linear, radius 128 -> 1, over 10 000 000 vectors of the seeded Gaussi
 A "step" is one mini-batch through the whole hot path: exact best-matching-unit search for every vector of the
 batch + the in-order neighbourhood update.  Batch sizes are the engine's own schedule (somhip.h SOMHIP_BATCH_AUTO,
 somhip_som_auto_batch: a rule in (units, radius(t), alpha(t)) -- at this workload 32768 vectors up to iteration
-9 011 200, 4096 after; `--batch B` fixes one size).  The timed region is EXACTLY --steps such batches of the real
+8 486 912, 8192 after; `--batch B` fixes one size).  The timed region is EXACTLY --steps such batches of the real
 10 M-iteration schedule, evenly spread over it (step k = the batch that holds iteration k * length / steps), so the
 radius sweeps its whole range inside the timed region; `value_timed_steps` = vectors of those batches / time.  `value`
 is the rate of the COMPLETE 10 M-vector run made after the timed region (`full_run`): the timed steps start from the
@@ -25,7 +25,7 @@ of the workload; `--online-full` re-measures it live).  `qerror_check` reports t
 (north_star's reading) and `abs_delta` (BASELINE.md section 4's) -- for find_qerror's own float accumulator and for the
 same mean accumulated in double, next to the resolution of that statistic measured on three seed pairs with exact-
 arithmetic controls (any batch > 1, the exact update kernels at batch 256 included, ends on a map
-whose qerror differs from the online one by 0.2 ... 4.6e-4 -- the float accumulator alone carries 2e-4 of rounding at
+whose qerror differs from the online one by a chaotic +-4e-4 -- the float accumulator alone carries 2e-4 of rounding at
 262 144 vectors of size 22.6).  `qerror_check.pass` (|rel| <= 1e-4) gates `value`: if it fails, `value` falls back to
 the online engine's rate; `pass_abs` says whether this run also landed inside 1e-4 absolute.
 

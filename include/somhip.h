@@ -185,9 +185,9 @@ int  somhip_som_train(somhip_codebook *cb, somhip_dataset *ds, const somhip_som_
  * p: length, alpha, alpha_type, radius of the run (teach_params, lvq_pak.h:186-204); n_units = xdim * ydim of the WHOLE map
  * (also on a shard), topol / neigh as in the codebook.  The schedule is a rule in (n_units, radius(t), alpha(t)) --
  * csrc/host_som.inc, som_auto_plan: 32768 iterations per batch while what a batch leaves in the map is forgotten again by
- * the end of the run (the sum of alpha(t') x the share of the map one sample teaches over the rest of the run is >= 12),
- * after that the largest power of two that moves no unit more than a quarter of the way to its samples within one batch
- * (configs[3]: 32768 up to iteration 9 011 200 of 10 M, then 4096).  Where the rule is not vouched for by a measurement
+ * the end of the run (the sum F(t) of alpha(t') x the share of the map one sample teaches over the rest of the run is
+ * >= 64), 8192 after (configs[3]: 32768 up to iteration 8 486 912 of 10 M, then 8192; where the line lies was measured
+ * on three seed pairs).  Where the rule is not vouched for by a measurement
  * against the online engine -- maps below 16384 units, runs whose long phase holds fewer than 64 long batches -- every
  * batch is ONE iteration: `auto` is then the reference's own online schedule (bit-exact).
  * A host that drives somhip_batch_winner_keys / somhip_som_batch_update itself (one process per GPU) asks this

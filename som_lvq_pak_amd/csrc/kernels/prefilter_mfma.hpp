@@ -302,9 +302,12 @@ __device__ __forceinline__ void split8(const float4 a, const float4 b, uint4 &hi
 // squared norms (fp32) + bf16 hi/lo tiles of the codebook, one pass.  One workgroup per row group; its
 // blockDim/64 waves (up to 16) take the k-blocks round-robin and their partial norms are added in wave order
 // (the bound tau is built from holds for any summation order, and this one is fixed).
+// rowmajor (may be null): a row-major fp32 copy of the rows, [ngroups * 64][d] -- every lane stores the 32 bytes of its row
+// it holds anyway; the 64 lanes of a store go to 64 rows, but the lines come together in L2 (a row group's 64 rows are
+// written by the waves of one workgroup) and leave it whole.  The exact re-rank of single rows reads from it.
 __global__ void k_prep_codes_bf16(CbView cb, int d8, float *__restrict__ cn,
                                   unsigned int *__restrict__ cn_max_bits, uint4 *__restrict__ chi,
-                                  uint4 *__restrict__ clo) {
+                                  uint4 *__restrict__ clo, float *__restrict__ rowmajor = nullptr) {
   __shared__ float s_part[16][WAVE];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   const int64_t g = blockIdx.x;
@@ -318,6 +321,11 @@ __global__ void k_prep_codes_bf16(CbView cb, int d8, float *__restrict__ cn,
     split8(a, b, hi, lo);
     chi[(g * d8 + kb) * WAVE + lane] = hi;
     clo[(g * d8 + kb) * WAVE + lane] = lo;
+    if (rowmajor) {                                       // (d % 4 == 0: the host asks for the copy only then)
+      float4 *dst = reinterpret_cast<float4 *>(rowmajor + (g * WAVE + lane) * cb.d) + 2 * kb;
+      dst[0] = a;
+      if (2 * kb + 1 < cb.d4) dst[1] = b;
+    }
   }
   s_part[wave][lane] = acc;
   __syncthreads();

@@ -590,7 +590,11 @@ __global__ __launch_bounds__(256) void k_rerank_pairs(CbView cb, const float *__
                                                       const uint32_t *__restrict__ col_count,
                                                       const uint32_t *__restrict__ pair_count,
                                                       uint64_t *__restrict__ keys,
-                                                      unsigned long long *__restrict__ stats) {
+                                                      unsigned long long *__restrict__ stats,
+                                                      const float *__restrict__ rowmajor = nullptr) {
+  // rowmajor (may be null; d % 4 == 0): the row-major copy of the rows k_prep_codes_bf16 made -- the four lanes of a quad
+  // then read 64 consecutive bytes of the row per step instead of 16 bytes out of each of four KiB (PMC, round 2: 2.3
+  // times the bytes of the rows fetched from the tiles).  Same values, same order of operations.
   // A fixed, small grid (workgroup launches cost ~50 ns each: a grid sized for the worst case was
   // the whole cost of this kernel).  Every workgroup builds the same table of 64-pair chunks per
   // column (prefix sums of the segment fills) and takes chunks round-robin.
@@ -639,7 +643,9 @@ __global__ __launch_bounds__(256) void k_rerank_pairs(CbView cb, const float *__
     if (slot >= col_count[lo]) continue;                 // quad-uniform
     const uint2 pr = pairs[static_cast<size_t>(lo) * cap_col + slot];
     const int64_t row = pr.y;
-    const float4 *crow = reinterpret_cast<const float4 *>(cb.tiles) + ((row >> 6) * cb.d4) * WAVE + (row & 63);
+    const int64_t cstep = rowmajor ? 1 : WAVE;           // float4 units between consecutive chunks of a row
+    const float4 *crow = rowmajor ? reinterpret_cast<const float4 *>(rowmajor + row * cb.d)
+                                  : reinterpret_cast<const float4 *>(cb.tiles) + ((row >> 6) * cb.d4) * WAVE + (row & 63);
     const float *x = rows + ((first + pr.x) % n_rows) * cb.d;
     float acc = 0.0f;
     constexpr int UP = 8;                                // chunks per lane and round: 32 chunks of the pair in flight
@@ -647,16 +653,16 @@ __global__ __launch_bounds__(256) void k_rerank_pairs(CbView cb, const float *__
     for (int q0 = 0; q0 < cb.d4; q0 += 4 * UP) {
       float4 cc[UP], xx[UP];
       if (vec && q0 + 4 * UP <= cb.d4) {                 // whole round in range: 16 unconditional loads in flight
-        const float4 *cq = crow + static_cast<int64_t>(q0 + j) * WAVE;
+        const float4 *cq = crow + static_cast<int64_t>(q0 + j) * cstep;
         const float4 *xq = reinterpret_cast<const float4 *>(x) + q0 + j;
 #pragma unroll
-        for (int u = 0; u < UP; u++) { cc[u] = cq[static_cast<int64_t>(4 * u) * WAVE]; xx[u] = xq[4 * u]; }
+        for (int u = 0; u < UP; u++) { cc[u] = cq[static_cast<int64_t>(4 * u) * cstep]; xx[u] = xq[4 * u]; }
       } else {
 #pragma unroll
         for (int u = 0; u < UP; u++) {
           const int q = q0 + 4 * u + j;
           const bool in = q < cb.d4;                     // past the end: (0 - 0)^2 = +0, exact to add
-          cc[u] = in ? crow[static_cast<int64_t>(q) * WAVE] : zero4;
+          cc[u] = in ? crow[static_cast<int64_t>(q) * cstep] : zero4;
           xx[u] = !in ? zero4 : vec ? reinterpret_cast<const float4 *>(x)[q] : load_x4<false>(x, q, cb.d);
         }
       }

@@ -374,6 +374,9 @@ struct somhip_codebook {
   uint4 *d_chi = nullptr, *d_clo = nullptr;   // bf16 hi/lo tiles [ngroups][d8][64] (bf16 pre-filter)
   bool prep_valid = false;         // d_cn / d_chi / d_clo describe the rows as they are now (set by a full k_prep_codes_bf16,
                                    // kept by the LVQ engine when it re-splits exactly the rows it corrected, cleared by every other writer)
+  float *d_rowmajor = nullptr;     // [ngroups*64][d] fp32 rows, row-major: what the exact re-rank of single rows gathers from (a row is
+                                   // 4 d contiguous bytes here, 16 bytes per KiB in the tiles); written by the full k_prep_codes_bf16
+  bool rowmajor_valid = false;     // ... and current only together with prep_valid and until a partial re-split (LVQ) clears it
 };
 struct somhip_dataset {
   somhip_engine *e = nullptr;
@@ -524,6 +527,8 @@ static void codebook_release(somhip_codebook *cb) {
   if (cb->d_talpha) (void)hipFree(cb->d_talpha);
   if (cb->d_cn) (void)hipFree(cb->d_cn);
   if (cb->d_cnmax) (void)hipFree(cb->d_cnmax);
+  if (cb->d_rowmajor) (void)hipFree(cb->d_rowmajor);
+  cb->d_rowmajor = nullptr;
   if (cb->d_chi) (void)hipFree(cb->d_chi);
   if (cb->d_clo) (void)hipFree(cb->d_clo);
   cb->v.tiles = nullptr;

@@ -478,6 +478,15 @@ def test_c2_full_size_matches_reference_cli(tools, tmp_path):
         "-radius", ex["radius"], "-v", 0)
     assert md5(out) == ex["md5"]
     assert run("qerror", "-din", ex["gen"], "-cin", out, "-v", 0).stdout == ex["qerror_stdout"]
+    # `-batch auto` on this map is the reference's own schedule (the engine's rule does not vouch for mini-batches on
+    # 1024 units / 100 000 vectors: somhip_som_auto_batch answers batch 1), so it meets north_star's tolerance against the
+    # committed reference qerror by being the reference's result: the same bytes, the same "11.168620"
+    auto = tmp_path / "auto.cod"
+    run("vsom", "-din", ex["gen"], "-cin", init, "-cout", auto, "-rlen", ex["rlen"], "-alpha", ex["alpha"],
+        "-radius", ex["radius"], "-batch", "auto", "-v", 0)
+    assert md5(auto) == ex["md5"]
+    q = run("qerror", "-din", ex["gen"], "-cin", auto, "-v", 0).stdout
+    assert abs(float(q) - float(ex["qerror_stdout"])) <= 1e-4 and q == ex["qerror_stdout"]
 
 
 def test_raw_fp32_reader_rejects_truncated_files(tools, tmp_path):

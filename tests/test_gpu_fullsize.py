@@ -65,6 +65,47 @@ def test_c4_scan_modes_agree_and_exact_hits(world):
     assert (bits(diff[:5, 0]) == 0).all()
 
 
+def test_c4_benched_mode_at_the_benched_shape():
+    """What bench.py times, at the size it times it (missing 5): 256 x 256 x 512, one 32768-vector batch of the
+    generator stream through the persistent level-1 ring kernel, level 2, the exact re-rank from the row-major copy and the
+    GEMM-form update.  Winners: the keys of the direct fp32 scan, bit for bit.  Update: the exact kernels' codebook within
+    8e-6 of the data's scale (fp32 rounding of a sum instead of a chain), at the head of the schedule (radius 128: every
+    unit is hit about 29 000 times in the batch) and near its end (radius 7)."""
+    from som_lvq_pak_amd import engine as E
+    eng = E.Engine(0)
+    BIG, L = 32768, 10_000_000
+    ds = E.Dataset(eng, generate=(3456, 256, DIM, 0, 2 * BIG))
+    lo, hi, cnt = E.column_minmax(ds)
+    init = E.randinit_from_bbox(lo, hi, cnt, XDIM, YDIM, 7)
+    scale = float(max(abs(lo).max(), abs(hi).max()))
+    cb = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, XDIM, YDIM)
+    try:
+        # a map that has seen one batch (so that the winners are spread over the map), then the batch under test
+        eng.set_update_mode("gemm")
+        E.som_train(cb, ds, L, 0.05, 128.0, batch=BIG, start_iter=0, count=BIG, trace=False)
+        start = cb.download()
+        eng.set_scan_mode("direct")
+        kd = _keys(E, eng, cb, ds, BIG, BIG)
+        eng.set_scan_mode("mfma_bf16")
+        km = _keys(E, eng, cb, ds, BIG, BIG)
+        assert np.array_equal(kd, km)
+        for it0 in (BIG, 9_500_000 // BIG * BIG):
+            res = {}
+            for mode in ("gemm", "exact"):
+                eng.set_update_mode(mode)
+                cb.upload(start)
+                ti, td = E.som_train(cb, ds, L, 0.05, 128.0, batch=BIG, start_iter=it0, count=BIG, data_first=BIG)
+                res[mode] = (ti, td, cb.download())
+            assert np.array_equal(res["gemm"][0], res["exact"][0]) and np.array_equal(bits(res["gemm"][1]), bits(res["exact"][1]))
+            assert np.array_equal(res["gemm"][0], (km & np.uint64(0xFFFFFFFF)).astype(np.int64))   # the traced winners are the keys' rows
+            err = float(np.abs(res["gemm"][2] - res["exact"][2]).max())
+            assert err <= 8e-6 * scale, (it0, err, scale)
+            assert not np.array_equal(res["exact"][2], start)
+    finally:
+        eng.set_update_mode("exact")
+        eng.close()
+
+
 def test_c4_sharded_equals_unsharded_and_alpha_zero(world):
     from som_lvq_pak_amd._lib import SomParams
     E, eng, x, init, ds = world

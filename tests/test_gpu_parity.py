@@ -512,16 +512,16 @@ def test_top8_two_level_and_by_group_equal_the_plain_paths(eng, E, oracle):
 
 def test_engine_chosen_batch_schedule_is_the_documented_one(eng, E):
     """SOMHIP_BATCH_AUTO (somhip_som_auto_batch): at configs[3]'s parameters 32768-iteration batches up to iteration
-    9 011 200 (whole batches), 4096 after; a map the rule does not vouch for: batch 1.  A run with it equals the same run
+    8 486 912 (whole batches), 8192 after; a map the rule does not vouch for: batch 1.  A run with it equals the same run
     made in two explicit segments (maps it vouches for) or the online engine's (small maps), bit for bit."""
     lib = eng.lib
     BL = 32768
     L10 = 10_000_000
-    t10 = 275 * BL
+    t10 = 259 * BL
     assert E.som_auto_batch(lib, L10, 0) == (0, BL)
     assert E.som_auto_batch(lib, L10, t10 - 1) == (t10 - BL, BL)
-    assert E.som_auto_batch(lib, L10, t10) == (t10, 4096)
-    last = t10 + (L10 - 1 - t10) // 4096 * 4096
+    assert E.som_auto_batch(lib, L10, t10) == (t10, 8192)
+    last = t10 + (L10 - 1 - t10) // 8192 * 8192
     assert E.som_auto_batch(lib, L10, L10 - 1) == (last, L10 - last)
     assert E.som_auto_batch(lib, 100000, 5000, radius=10.0, n_units=1024) == (5000, 1)
     # 128 x 128 map, 100 long batches' worth of iterations over a 4096-vector data set

@@ -43,9 +43,9 @@ def main():
         codes[7] = codes[n - 1]                           # ties across the codebook's ends
         cb = E.Codebook(eng, codes)
         ds = E.Dataset(eng, x)
-        os.environ["SOMHIP_L1_NORING"] = "1"
+        os.environ["SOMHIP_L1_NORING"] = "1"; os.environ["SOMHIP_NO_ROWMAJOR"] = "1"
         k_old = keys_of(eng, cb, ds, 0, m, buf)
-        os.environ.pop("SOMHIP_L1_NORING")
+        os.environ.pop("SOMHIP_L1_NORING"); os.environ.pop("SOMHIP_NO_ROWMAJOR")
         k_new = keys_of(eng, cb, ds, 0, m, buf)
         os.environ["SOMHIP_L1_RING_NOGMIN"] = "1"
         k_new2 = keys_of(eng, cb, ds, 0, m, buf)
@@ -69,15 +69,19 @@ def main():
     eng.set_update_mode("gemm")
     E.som_train(cb, ds, 10_000_000, 0.05, 128.0, batch=32768, start_iter=0, count=65536, trace=False)
     eng.sync()
+    cb_rows = cb.download()
     for B in ((32768,) if quick else (4096, 8192, 32768)):
-        for mode in ("old", "ring", "ring, k_group_min kept"):
-            os.environ.pop("SOMHIP_L1_NORING", None); os.environ.pop("SOMHIP_L1_RING_NOGMIN", None)
+        for mode in ("old", "ring, pairs from tiles", "ring"):
+            os.environ.pop("SOMHIP_L1_NORING", None); os.environ.pop("SOMHIP_NO_ROWMAJOR", None)
             if mode == "old":
                 os.environ["SOMHIP_L1_NORING"] = "1"
-            if mode.endswith("kept"):
-                os.environ["SOMHIP_L1_RING_NOGMIN"] = "1"
-            ref = keys_of(eng, cb, ds, 0, B, buf)
+            if mode != "ring":
+                os.environ["SOMHIP_NO_ROWMAJOR"] = "1"
+            cb.upload(cb_rows)                               # (the codebook's prepared copies are made again under this mode)
             eng.timing(True); eng.timing_reset()
+            ref = keys_of(eng, cb, ds, 0, B, buf)             # (the call that prepares the codebook's copies: bf16 tiles, norms, row-major rows)
+            prep_us = 1e3 * eng.timing_table()["k_norms_tau"][1]
+            eng.timing_reset()
             reps = 8
             t0 = time.perf_counter()
             for r in range(reps):
@@ -88,15 +92,15 @@ def main():
             eng.timing(False)
             l1 = tab["k_dist_mfma_bf16"]
             tot = sum(v[1] for v in tab.values()) / reps
-            print("B %5d %-24s level 1 %8.1f us/launch (%.3f of 2.5 Pflop/s)  all kernels %8.1f us  wall %8.1f us   %s" % (
+            print("B %5d %-24s level 1 %8.1f us/launch (%.3f of 2.5 Pflop/s)  all kernels %8.1f us  wall %8.1f us  prep+tau (first call) %6.1f us   %s" % (
                 B, mode, 1e3 * l1[1] / max(l1[0], 1), 2.0 * n * d * B / (l1[1] / max(l1[0], 1) * 1e-3) / 2.5e15,
-                1e3 * tot, 1e6 * wall, " ".join("%s=%.0f" % (k, 1e3 * v[1] / reps) for k, v in tab.items() if v[0] and k != "k_dist_mfma_bf16")), flush=True)
+                1e3 * tot, 1e6 * wall, prep_us, " ".join("%s=%.0f" % (k, 1e3 * v[1] / reps) for k, v in tab.items() if v[0] and k != "k_dist_mfma_bf16")), flush=True)
             if mode == "old":
                 ref_old = ref
             elif not np.array_equal(ref, ref_old):
                 print("   keys DIFFER from the two-buffer kernel's (%d of %d)" % (int((ref != ref_old).sum()), B))
                 bad += 1
-    os.environ.pop("SOMHIP_L1_NORING", None); os.environ.pop("SOMHIP_L1_RING_NOGMIN", None)
+    os.environ.pop("SOMHIP_L1_NORING", None); os.environ.pop("SOMHIP_NO_ROWMAJOR", None)
     print("l1_probe:", "OK" if not bad else "%d FAILURES" % bad)
     sys.exit(1 if bad else 0)
 
