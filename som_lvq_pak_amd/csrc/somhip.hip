@@ -82,13 +82,14 @@ enum KernelId {
   KID_LVQ_COMPONENTS,
   KID_SOM_UPDATE_GEMM,
   KID_DIST_L2,
+  KID_L2_SELECT,
   KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {
     "k_scan_exact", "k_som_update_run", "k_som_online_step", "k_lvq_online_step",
     "k_pack_samples", "k_merge_topk", "k_scan_masked", "k_layout", "k_decode_winners",
     "k_dist_mfma", "k_rerank", "k_norms_tau", "k_som_members",
-    "k_rerank_select", "k_rerank_pairs", "k_dist_mfma_bf16", "k_lvq_batch_apply", "k_som_update_bubble_s", "k_lvq_components", "k_som_update_gemm", "k_dist_l2"};
+    "k_rerank_select", "k_rerank_pairs", "k_dist_mfma_bf16", "k_lvq_batch_apply", "k_som_update_bubble_s", "k_lvq_components", "k_som_update_gemm", "k_dist_l2", "k_l2_select"};
 extern "C" int somhip_kernel_count(void) { return KID_COUNT; }
 extern "C" const char *somhip_kernel_name(int i) { return (i >= 0 && i < KID_COUNT) ? kKernelNames[i] : ""; }
 

@@ -567,18 +567,18 @@ def test_vsom_gpus_with_exchanged_bounds(tools, tmp_path):
 @pytest.mark.gpu
 def test_vsom_batch_auto(tools, tmp_path):
     """vsom -batch auto: the engine's own batch boundaries (somhip_som_auto_batch, a rule in (units, radius, alpha)).  On a
-    map the rule vouches for (128 x 128, 80 long batches and more): one GPU == three ranks (every rank asks the library for
-    the same boundaries), and != a fixed -batch 4096 run (the schedule really differs).  On a small map `auto` is the
+    map the rule vouches for (128 x 128, 100 long batches' worth of iterations): one GPU == two ranks (every rank asks the library for
+    the same boundaries), and != a fixed -batch 32768 run (the schedule really differs).  On a small map `auto` is the
     reference's own online schedule: the bytes of -batch 1 (= no -batch flag at all)."""
-    g = "gen:k=6,dim=8,n=20000,seed=5"
+    g = "gen:k=6,dim=8,n=40000,seed=5"          # (at least one long batch of rows: the fast update kernels take no run longer than the data)
     init = tmp_path / "a_init.cod"
     run("randinit", "-din", g, "-cout", init, "-xdim", 128, "-ydim", 128, "-topol", "hexa", "-neigh", "bubble", "-rand", 4, "-v", 0)
-    L = 80 * 32768 + 5000
+    L = 100 * 32768 + 5000                       # (the rule wants >= 64 long batches before its short ones: with 80 it answers batch 1)
     common = ["-din", g, "-cin", init, "-rlen", L, "-alpha", 0.05, "-radius", 64, "-v", 0]
-    a, b, c = tmp_path / "auto1.cod", tmp_path / "auto3.cod", tmp_path / "fixed.cod"
+    a, b, c = tmp_path / "auto1.cod", tmp_path / "auto2.cod", tmp_path / "fixed.cod"
     run("vsom", *common, "-batch", "auto", "-cout", a)
-    run("vsom", *common, "-batch", "auto", "-cout", b, "-gpus", 3)
-    run("vsom", *common, "-batch", 4096, "-cout", c)
+    run("vsom", *common, "-batch", "auto", "-cout", b, "-gpus", 2)
+    run("vsom", *common, "-batch", 32768, "-cout", c)
     assert md5(a) == md5(b)
     assert md5(a) != md5(c)
     small = tmp_path / "s_init.cod"
@@ -675,3 +675,74 @@ def test_reference_tools_linked_with_the_glue(tmp_path):
         _run_ref(lvq, "-type", ex["tool"], "-din", os.path.join(DATA, "ex1.dat"), "-cin", os.path.join(CLI, "lvq_init.cod"),
                  "-cout", out, *ex["args"], "-v", 0, env={"SOMHIP_SELFUNCS": "hip"})
         assert md5(out) == ex["md5"], tag
+
+
+@pytest.mark.gpu
+def test_reference_scanners_and_buffers_through_the_glue(tmp_path):
+    """VERDICT r2 item 6.  (a) The reference's scanners that call teach->winner once per data vector -- accuracy.o
+    (compute_accuracy, accuracy.c:80-113), vcal.o (find_labels, vcal.c:106-129), visual.o, classify.o, knntest.o, unmodified
+    -- with `-selfuncs hip`: the glue's winner answers from ONE GPU scan of the data list (stderr at -v 2 says so) and the
+    tools print / write the reference's bytes, with and without -buffer.  (b) -buffer N training through the glue: one data
+    set per loaded buffer, the reference's own loads and -rand shuffles: the reference's .cod and snapshot bytes
+    (tests/golden/cli/expected.json buffer_rand / buffer_snap).  (c) -batch B read by the glue with extract_parameter."""
+    t = EXPECTED["lvq"]["tools"]
+    cod = os.path.join(CLI, "lvq_olvq1.cod")
+    ex2 = os.path.join(DATA, "ex2.dat")
+    # ---- (a) scanners
+    acc = _glued("accuracy_hip")
+    cpu = _run_ref(acc, "-din", ex2, "-cin", cod, "-v", 0).stdout                   # the same binary's CPU row
+    for extra in ([], ["-buffer", 300]):
+        p = _run_ref(acc, "-din", ex2, "-cin", cod, "-selfuncs", "hip", "-v", 2, *extra)
+        assert p.stdout == cpu and "Total accuracy" in cpu, extra
+        assert "data vectors against 200 codes on the GPU" in p.stderr, p.stderr
+        assert p.stderr.count("on the GPU") == (1 if not extra else 7)                # 1962 vectors: one scan, or one per buffer of 300
+    p = _run_ref(acc, "-din", ex2, "-cin", os.path.join(CLI, "lvq_init.cod"), "-selfuncs", "hip", "-v", 0)
+    assert p.stdout == _run_ref(acc, "-din", ex2, "-cin", os.path.join(CLI, "lvq_init.cod"), "-v", 0).stdout
+    kn = _glued("knntest_hip")
+    for knn in (1, 3, 5):
+        p = _run_ref(kn, "-din", ex2, "-cin", cod, "-knn", knn, "-selfuncs", "hip", "-v", 0)
+        assert p.stdout == t["knntest_%d" % knn], knn
+    cl = _glued("classify_hip")
+    _run_ref(cl, "-din", ex2, "-cin", cod, "-dout", tmp_path / "cls.dat", "-cfout", tmp_path / "cls.cfo", "-selfuncs", "hip", "-v", 0)
+    assert md5(tmp_path / "cls.dat") == t["classify_dout_md5"] and md5(tmp_path / "cls.cfo") == t["classify_cfout_md5"]
+    som = os.path.join(CLI, EXPECTED["som"]["hexa_bubble"]["init"])
+    exd = os.path.join(DATA, "ex.dat")
+    vcal, vis = _glued("vcal_hip"), _glued("visual_hip")
+    fts = os.path.join(DATA, "ex_fts.dat")                                          # labelled data (vcal needs labels)
+    for extra in ([], ["-buffer", 100]):
+        _run_ref(vcal, "-din", fts, "-cin", som, "-cout", tmp_path / "cal_cpu.cod", "-v", 0, *extra)
+        p = _run_ref(vcal, "-din", fts, "-cin", som, "-cout", tmp_path / "cal_hip.cod", "-selfuncs", "hip", "-v", 2, *extra)
+        assert md5(tmp_path / "cal_cpu.cod") == md5(tmp_path / "cal_hip.cod") and "on the GPU" in p.stderr, extra
+    _run_ref(vis, "-din", exd, "-cin", som, "-dout", tmp_path / "vis_cpu.out", "-v", 0)
+    _run_ref(vis, "-din", exd, "-cin", som, "-dout", tmp_path / "vis_hip.out", "-selfuncs", "hip", "-v", 0)
+    assert md5(tmp_path / "vis_cpu.out") == md5(tmp_path / "vis_hip.out")
+    # ---- (b) -buffer N training: the reference's bytes
+    vsom, lvq = _glued("vsom_hip"), _glued("lvqtrain_hip")
+    for group in ("buffer_rand", "buffer_snap"):
+        for tag, ex in EXPECTED[group].items():
+            if "-buffer" not in [str(a) for a in ex["args"]]:
+                continue
+            out = tmp_path / (tag + ".cod")
+            snap = ["-snapfile", str(tmp_path / (tag + "_%ld.snap"))] if "snapshots" in ex else []
+            if ex["tool"] == "vsom":
+                _run_ref(vsom, "-din", os.path.join(DATA, ex["data"]), "-cin", os.path.join(CLI, ex["cin"]), "-cout", out, *ex["args"],
+                         *snap, "-selfuncs", "hip", "-v", 0)
+            else:
+                _run_ref(lvq, "-type", ex["tool"], "-din", os.path.join(DATA, ex["data"]), "-cin", os.path.join(CLI, ex["cin"]), "-cout", out,
+                         *ex["args"], *snap, "-v", 0, env={"SOMHIP_SELFUNCS": "hip"})
+            assert md5(out) == ex["md5"], tag
+            for it, want in ex.get("snapshots", {}).items():
+                assert md5(tmp_path / ("%s_%s.snap" % (tag, it))) == want, (tag, it)
+    # qerror over a buffered data file
+    ex = EXPECTED["som"]["hexa_bubble"]
+    trained = tmp_path / "hb.cod"
+    _run_ref(vsom, "-din", exd, "-cin", os.path.join(CLI, ex["init"]), "-cout", trained, "-rlen", ex["rlen"], "-alpha", ex["alpha"],
+             "-radius", ex["radius"], "-selfuncs", "hip", "-v", 0)
+    assert _run_ref(_glued("qerror_hip"), "-din", exd, "-cin", trained, "-buffer", 700, "-selfuncs", "hip", "-v", 0).stdout == ex["qerror_stdout"]
+    # ---- (c) -batch B through the glue == the product's vsom -batch B (same engine call)
+    a, b = tmp_path / "gb.cod", tmp_path / "pb.cod"
+    _run_ref(vsom, "-din", exd, "-cin", os.path.join(CLI, ex["init"]), "-cout", a, "-rlen", 2000, "-alpha", 0.05, "-radius", 8,
+             "-batch", 64, "-selfuncs", "hip", "-v", 0)
+    _run_ref(os.path.join(BIN, "vsom"), "-din", exd, "-cin", os.path.join(CLI, ex["init"]), "-cout", b, "-rlen", 2000, "-alpha", 0.05,
+             "-radius", 8, "-batch", 64, "-v", 0)
+    assert md5(a) == md5(b) and md5(a) != ex["md5"]
