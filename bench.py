@@ -132,7 +132,7 @@ def git_head():
 
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot run the profiler on itself)."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json",):
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", name)))
             j["file"] = "profiles/" + name
@@ -492,7 +492,7 @@ def bench_som(a):
             if k is None:                                       # template / variant suffixes (k_dist_mfma_bf16_wide)
                 hits = [v for n, v in ks.items() if n.startswith(r["kernel"] + "_")]
                 k = hits[0] if len(hits) == 1 else None
-            if k and (xdim, ydim, d, world) == (256, 256, 512, 1) and pmc.get("batch", "4096") == bdesc:
+            if k and (xdim, ydim, d, world) == (256, 256, 512, 1) and auto_b and pmc.get("schedule") == "auto":
                 r["traffic"] = {"bytes_per_launch": k["bytes"], "read": k["read_bytes"], "write": k["write_bytes"],
                                 "source": "%s (commit %s): %s" % (pmc.get("file"), pmc.get("commit", "round 1"), pmc.get("source", ""))}
             return r

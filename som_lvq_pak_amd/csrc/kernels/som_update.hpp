@@ -46,7 +46,8 @@ struct MemberEntry { uint32_t sample; float alpha; unsigned long long mask; };  
 constexpr int LIST_PAD = 8;
 __host__ __device__ __forceinline__ int64_t list_stride(int64_t count) { return count + LIST_PAD; }
 
-template <bool GAUSS, int NT>          // NT threads: 256, or 1024 when a small shard has few row groups to spread
+template <bool GAUSS, int NT, int RRT = 4>   // NT threads: 256, or 1024 when a small shard has few row groups to spread / the lists
+                                             // will not be cut short; RRT samples per thread and trip
 __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
                                                      const int2 *__restrict__ bxy,
                                                      const uint64_t *__restrict__ keys,
@@ -56,16 +57,22 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
                                                      unsigned long long *__restrict__ stats,
                                                      int64_t xoff_first = -1, int64_t xoff_rows = 0,
                                                      int xoff_scale = 0, uint32_t tail_need = 0,
-                                                     uint32_t *__restrict__ lstart = nullptr, int gauss_gemm = 0) {
+                                                     uint32_t *__restrict__ lstart = nullptr, int gauss_gemm = 0,
+                                                     int reach_max = -1) {
+  // reach_max >= 0 (with decoded winners, bubble): the largest `reach` of the run's iterations.  A winner whose box of
+  // that reach misses the group is dropped on its 8 bytes of coordinates alone -- the 16 bytes of its step scalars are
+  // only fetched for the samples that pass.  (With small neighbourhoods every workgroup otherwise reads the scalars of
+  // every sample of the run to reject nearly all of them: 1024 groups x 32768 samples x 24 bytes through L2 per launch.)
   // gauss_gemm (GAUSS only; the consumer is K4m's gaussian form): the entry's mask field carries the winner's lattice
   // coordinates (x | y << 10, 10 bits each), 8 bits of remainder of, and in its upper word the float log2(e) / (2 radius^2) of the iteration; samples whose
   // rate would be below 2^-40 of alpha for every unit of the group are left out
   // xoff_first >= 0 (the consumer is K4s): the entry carries, instead of the sample's index in the run, where its
   // row starts in the data array in float4 units -- ((xoff_first + index) mod xoff_rows) * d / 4 -- so that the
   // update kernel's scalar unit adds instead of wrapping and multiplying per entry
-  constexpr int RR = 4;                 // samples per thread and trip: their loads are issued together
+  constexpr int RR = RRT;               // samples per thread and trip: their loads are issued together
   constexpr int NW = NT / 64;
-  static_assert(RR * NW <= 64, "the (round, wave) counts are scanned by one wavefront");
+  constexpr int SC = (RR * NW + 63) / 64;   // (round, wave) counts per lane of the wavefront that scans them
+  static_assert(RR * NW <= 256, "the (round, wave) counts are scanned by one wavefront, up to four per lane");
   __shared__ uint32_t s_wcount[RR * NW + 1];             // counts, then exclusive prefix (+ total) per trip
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t g = blockIdx.x;
@@ -93,6 +100,15 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
   // is the last ~500 of a batch's 16 384 samples instead of all of them.
   __shared__ uint32_t s_full;
   if (tid == 0) s_full = 0u;
+  // Two phases per trip (bubble, decoded winners).  Deciding membership is ~200 vector instructions per sample (eight
+  // lattice rows, an integer square root each), and a wavefront pays them whenever ONE of its 64 samples is near the group:
+  // with the samples in stream order that is nearly every wavefront from radius ~10 up, although only a tenth of the
+  // samples are near (step_probe.py: 0.48 ms per 32768 vectors at radius 20-33, 0.27 ms at radius 2).  So the trip's
+  // samples first go through the cheap box test and the near ones are queued in LDS, in sample order; the membership
+  // arithmetic then runs over the queue with every lane busy.  The order of the entries -- queue order = sample order --
+  // and every value in them are unchanged.
+  __shared__ uint16_t s_q[NT * RR];
+  const bool prepass = !GAUSS && !keys && reach_max >= 0;
   const bool tail = tail_need != 0u;
   uint32_t pos_end = static_cast<uint32_t>(count);
   const int64_t ntrips = (count + NT * RR - 1) / (NT * RR);
@@ -101,14 +117,61 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
     const int64_t b0 = tail ? count - (trip + 1) * (NT * RR) : trip * (NT * RR);   // (tail: may start below 0)
     unsigned long long mm[RR];
     float al[RR];
+    int64_t bb[RR];
+    uint32_t n_near = NT * RR;
+    if (prepass) {
+      // phase A: winners whose box of reach_max (>= every iteration's reach) touches the group, queued in sample order
+      bool nr[RR];
+      unsigned long long balq[RR];
+#pragma unroll
+      for (int r = 0; r < RR; r++) {
+        const int64_t b = b0 + NT * r + tid;
+        nr[r] = false;
+        if (b >= 0 && b < count) {
+          const int2 w = bxy[b];
+          nr[r] = w.x >= 0 && w.y + reach_max >= g_ty0 && w.y - reach_max <= g_ty1 && w.x + reach_max >= g_txa && w.x - reach_max <= g_tx1;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RR; r++) {
+        balq[r] = __ballot(nr[r]);
+        if (lane == 0) s_wcount[r * NW + wave] = __popcll(balq[r]);
+      }
+      __syncthreads();
+      if (wave == 0) {
+        uint32_t cc[SC], c = 0;                          // lane l: counts SC l .. SC l + SC - 1
+#pragma unroll
+        for (int k = 0; k < SC; k++) { cc[k] = SC * lane + k < RR * NW ? s_wcount[SC * lane + k] : 0u; c += cc[k]; }
+        uint32_t inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t o = __shfl_up(inc, off, WAVE);
+          if (lane >= off) inc += o;
+        }
+        uint32_t run = inc - c;
+#pragma unroll
+        for (int k = 0; k < SC; k++) { if (SC * lane + k < RR * NW) s_wcount[SC * lane + k] = run; run += cc[k]; }
+        if (lane == 63) s_wcount[RR * NW] = inc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < RR; r++)
+        if (nr[r]) s_q[s_wcount[r * NW + wave] + __popcll(balq[r] & ((1ull << lane) - 1))] = static_cast<uint16_t>(NT * r + tid);
+      n_near = s_wcount[RR * NW];
+      __syncthreads();                                   // the queue is whole; s_wcount is free for phase B
+    }
 #pragma unroll
     for (int r = 0; r < RR; r++) {
-      const int64_t b = b0 + NT * r + tid;
+      // phase B: queue position NT r + tid (without the queue: the trip's sample of that number)
+      const uint32_t qpos = static_cast<uint32_t>(NT * r + tid);
+      const int64_t b = b0 + (prepass ? static_cast<int64_t>(qpos < n_near ? s_q[qpos] : 0) : static_cast<int64_t>(qpos));
+      bb[r] = b;
       unsigned long long m = 0;
       float alpha_b = 0.f;
-      if (b >= 0 && b < count) {
+      bool near = qpos < n_near && b >= 0 && b < count;
+      int2 w = make_int2(-1, -1);
+      if (near) {
       const StepScalars s = sc[b];
-      int2 w;
       if (keys) {                                        // winners decoded here (K4a's rule), no extra launch
         w = make_int2(-1, -1);
         if (s.reach >= 0) {
@@ -216,15 +279,19 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
     if (tail && lane == 0 && nfull) atomicAdd(&s_full, nfull);
     __syncthreads();
     if (wave == 0) {
-      const uint32_t c = lane < RR * NW ? s_wcount[lane] : 0u;
+      uint32_t cc[SC], c = 0;                            // lane l: counts SC l .. SC l + SC - 1
+#pragma unroll
+      for (int k = 0; k < SC; k++) { cc[k] = SC * lane + k < RR * NW ? s_wcount[SC * lane + k] : 0u; c += cc[k]; }
       uint32_t inc = c;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = __shfl_up(inc, off, WAVE);
         if (lane >= off) inc += o;
       }
-      if (lane < RR * NW) s_wcount[lane] = inc - c;
-      if (lane == RR * NW - 1) s_wcount[RR * NW] = inc;
+      uint32_t run = inc - c;
+#pragma unroll
+      for (int k = 0; k < SC; k++) { if (SC * lane + k < RR * NW) s_wcount[SC * lane + k] = run; run += cc[k]; }
+      if (lane == 63) s_wcount[RR * NW] = inc;
     }
     __syncthreads();
 #pragma unroll
@@ -232,7 +299,7 @@ __global__ __launch_bounds__(NT) void k_som_members(CbView cb, int64_t count,
       const unsigned long long m = mm[r];
       if (m != 0) {
         MemberEntry e;
-        const int64_t bidx = b0 + NT * r + tid;
+        const int64_t bidx = bb[r];
         e.sample = xoff_first < 0 ? static_cast<uint32_t>(bidx)
                                   : static_cast<uint32_t>(((xoff_first + bidx) % xoff_rows) * xoff_scale);   // scale: d/4 (float4 units) or 4 d (bytes)
         e.alpha = al[r]; e.mask = m;

@@ -146,6 +146,7 @@ struct somhip_engine {
   bool l2_lds_attr_set = false;                // ... and for k_dist_l2_lds
   bool l1r_attr_set = false;                   // ... and for k_dist_mfma_bf16_l1r
   int n_cus = 0;                               // compute units of the device (grid of the persistent kernels)
+  int online_u = 8;                            // register-buffer depth of the online step kernel in use (SOMHIP_ONLINE_U)
   LvqCtl *lvq_hctl = nullptr;                  // pinned: read-backs of the LVQ batch loop's control block, one per batch in flight
   hipEvent_t lvq_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };

@@ -890,6 +890,58 @@ def test_fixed_points_beyond_the_edge_of_the_map(eng, E, oracle, neigh):
             cb.close(); ds.close()
 
 
+@pytest.mark.parametrize("radius,topol", [(24.0, 3), (6.0, 3), (9.0, 4)])
+def test_long_batches_take_the_decoded_winner_path_and_equal_the_oracle(eng, E, oracle, radius, topol):
+    """Runs of >= 16384 iterations decode the winners once (k_decode_winners) and k_som_members queues the samples near a
+    row group before it decides membership (two phases per trip, round 3): member lists in iteration order with the exact
+    lattice test -- checked the only way that does not share the code under test: the exact update kernels on a
+    20 000-iteration batch against the batch oracle, codebook bits and winner traces (hexa and rect, the neighbourhood
+    a few patches or a good part of the 64 x 48 map wide, a run that wraps around the data and is cut by fixed points)."""
+    rs = np.random.RandomState(11)
+    x, _ = synth(83, 6000, 8, k=9, spread=3.0)
+    fixed = np.full((6000, 2), -1, dtype=np.int16)
+    for r in rs.choice(6000, 30, replace=False):
+        fixed[r] = (rs.randint(0, 64), rs.randint(0, 48))
+    ini = oracle.randinit(x, 64, 48, 4)
+    L, B = 40000, 20000
+    oc, oi, od = oracle.som_train(ini, 64, 48, topol, 1, x, L, 0.06, radius, fixed_xy=fixed, fixed_on=1, batch=B)
+    cb = E.Codebook(eng, ini, topol, 1, 64, 48)
+    ds = E.Dataset(eng, x, fixed_xy=fixed)
+    ti, td = E.som_train(cb, ds, L, 0.06, radius, use_fixed=1, batch=B)
+    assert np.array_equal(ti, oi) and np.array_equal(bits(td), bits(od))
+    assert np.array_equal(bits(cb.download()), bits(oc))
+    cb.close(); ds.close()
+
+
+def test_long_batches_gemm_form_tail_lists_equal_full_lists(eng, E, monkeypatch):
+    """The same path in update mode gemm (dims in whole 128s): k_som_members in tail mode -- only the end of every list
+    is made, the trips run from the end of the batch -- must give k_som_update_gemm what whole lists give it, bit for
+    bit (SOMHIP_GEMM_FULL_LISTS=1), at a radius where the tail is cut short and at one where it is the whole list; and
+    the result stays within fp32 rounding of the exact kernels'."""
+    x, _ = synth(84, 20000, 128, k=7, spread=3.0)
+    rs = np.random.RandomState(5)
+    ini = (x[rs.randint(0, 20000, 64 * 48)] + 0.2 * rs.standard_normal((64 * 48, 128))).astype(np.float32)
+    ds = E.Dataset(eng, x)
+    scale = float(np.abs(x).max())
+    for radius, it0 in ((24.0, 0), (5.0, 60000)):
+        out = {}
+        for tag, mode, env in (("tail", "gemm", None), ("full", "gemm", "1"), ("exact", "exact", None)):
+            if env:
+                monkeypatch.setenv("SOMHIP_GEMM_FULL_LISTS", env)
+            else:
+                monkeypatch.delenv("SOMHIP_GEMM_FULL_LISTS", raising=False)
+            eng.set_update_mode(mode)
+            cb = E.Codebook(eng, ini, 3, 1, 64, 48)
+            ti, _ = E.som_train(cb, ds, 100000, 0.05, radius, batch=20000, start_iter=it0, count=20000, data_first=0)
+            out[tag] = (ti, cb.download())
+            cb.close()
+        eng.set_update_mode("exact")
+        monkeypatch.delenv("SOMHIP_GEMM_FULL_LISTS", raising=False)
+        assert np.array_equal(out["tail"][0], out["exact"][0])
+        assert np.array_equal(bits(out["tail"][1]), bits(out["full"][1])), radius
+        assert float(np.abs(out["tail"][1] - out["exact"][1]).max()) <= 8e-6 * scale, radius
+
+
 def test_patch_row_order_masks_fixed_weights_and_shards(eng, E, oracle):
     import ctypes as C
     from som_lvq_pak_amd._lib import SomParams

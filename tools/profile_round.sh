@@ -3,7 +3,7 @@
 # same command, and the PMC passes (each counter set in its own run, kernel-trace only).
 # Everything lands under gpurun_out/prof_<tag>/; copy what is to be judged into profiles/.
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT

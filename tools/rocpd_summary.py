@@ -52,15 +52,15 @@ def main():
     f = counters(f"{src}/pmc_FETCH_SIZE/p_results.db")
     w = counters(f"{src}/pmc_WRITE_SIZE/p_results.db")
     note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), "
-            "bench.py --steps 8 --warmup 1 --no-full-run: 8 batches of the engine-chosen schedule (six of 32768 vectors, two of 8192) "
+            "bench.py --steps 8 --warmup 1 --no-full-run: 8 batches of the engine-chosen schedule (seven of 32768 vectors, one of 8192) "
             "spread over the 10 M-iteration schedule (radius 128 -> 17); FETCH_SIZE x2 (gfx950), per-launch averages")
-    bdesc = "engine-chosen (32768 over the first three quarters of the schedule, 8192 after)"
+    bdesc = "engine-chosen (somhip_som_auto_batch: 32768 up to iteration 8486912, 8192 after)"
     res = {}
     for k in sorted(set(f) | set(w)):
         rd = 2.0 * f.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
         wr = w.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
         res[k] = {"read_bytes": rd, "write_bytes": wr, "bytes": rd + wr}
-    json.dump({"source": note, "commit": commit, "batch": bdesc, "kernels": res}, open(f"{dst}/{tag}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
+    json.dump({"source": note, "commit": commit, "batch": bdesc, "schedule": "auto", "kernels": res}, open(f"{dst}/{tag}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
     with open(f"{dst}/{tag}_pmc_hbm_traffic.txt", "w") as o:
         o.write(f"# {note}\n# Calibration: k_rows_to_tiles reads 128 MiB and writes 128 MiB.\n")
         o.write(f"{'kernel':<28}{'read MiB':>14}{'write MiB':>15}\n")
