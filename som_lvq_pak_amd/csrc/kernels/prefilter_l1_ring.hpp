@@ -28,6 +28,12 @@
 
 namespace somhip {
 
+// L1R_ABLATE (measurement builds only: make lib EXTRA=-DL1R_ABLATE=n LIB=...; results are then wrong by design):
+//   1 no epilogue arithmetic, 2 no LDS-DMA requests inside the stages, 3 no fragment reads inside the stages,
+//   4 no MFMAs -- what the kernel costs without each part (tools/l1_probe.py --quick, profiles/r03_l1_ablation.txt)
+#ifndef L1R_ABLATE
+#define L1R_ABLATE 0
+#endif
 constexpr int L1R_NS = 4;                   // ring slots
 constexpr int L1R_TOT = 2048;               // uint4 per slot: 4 groups x 4 k-blocks x 64 rows + 8 sample tiles x 4 k-blocks x 32
 constexpr int L1R_RED = 16 * 256;           // floats: [4 groups][4 row quarters][256 samples]
@@ -140,10 +146,14 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1r(CbView cb, int d8
   int q = 0;                                              // the stage being multiplied, over all tiles
 #define L1R_COL(J)                                                                                                     \
   do {                                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                      \
-      acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ca[i]), __builtin_bit_cast(bf16x8, bfr[J]), acc[i][J], 0, 0, 0); \
-    l1r_read<2048 * ((J) >> 1) + 256 * ((J) & 1)>(bfr[J], nb);                                                         \
-    if ((J) < 4) l1r_read<256 * ((J) & 3)>(na[(J) & 3], nab);                                                          \
+    if (L1R_ABLATE != 4) {                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                    \
+        acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ca[i]), __builtin_bit_cast(bf16x8, bfr[J]), acc[i][J], 0, 0, 0); \
+    }                                                                                                                  \
+    if (L1R_ABLATE != 3) {                                                                                             \
+      l1r_read<2048 * ((J) >> 1) + 256 * ((J) & 1)>(bfr[J], nb);                                                       \
+      if ((J) < 4) l1r_read<256 * ((J) & 3)>(na[(J) & 3], nab);                                                        \
+    }                                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
   } while (0)
   auto stage = [&](l1r_u32x4 (&ca)[4], l1r_u32x4 (&na)[4]) {
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1r(CbView cb, int d8
     // if both made their four requests now (60 cycles and more each, MI355X_MICROARCH.md) the matrix pipe of their SIMD
     // would stand still for that long -- waves 0 .. 3 make them here, waves 4 .. 7 behind their fourth column of MFMAs,
     // so that each wave's requests go out under its partner's MFMAs
-    if (wave < 4) issue();
+    if (L1R_ABLATE != 2 && wave < 4) issue();
     const uint32_t slot_b = static_cast<uint32_t>((q + 1) & (NS - 1)) * (TOT * 16u);
     const uint32_t nab = fa_b + slot_b, nb = fb_b + slot_b;
     // b0 .. b3 and a0 .. a3 of stage q are back once at most the four reads behind them (b4 .. b7) are outstanding
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1r(CbView cb, int d8
     // fragment of that column is refilled in place, and -- behind the first four columns -- one code fragment goes into
     // the other set (sched_barrier: the order written here is the order issued)
     L1R_COL(0); L1R_COL(1); L1R_COL(2); L1R_COL(3);
-    if (wave >= 4) issue();
+    if (L1R_ABLATE != 2 && wave >= 4) issue();
     // b4 of stage q: behind it b5 b6 b7 and the eight reads just made
     asm volatile("s_waitcnt lgkmcnt(11)" : "+v"(bfr[4]));
     L1R_COL(4);
@@ -227,13 +237,14 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1r(CbView cb, int d8
     for (int j = 0; j < 8; j++) {
       float m = 3.4e38f;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < (L1R_ABLATE == 1 ? 1 : 4); i++) {
         m = fminf(m, fminf(__builtin_fmaf(-2.0f, acc[i][j][0], cnv[i].x), __builtin_fmaf(-2.0f, acc[i][j][1], cnv[i].y)));
+        if (L1R_ABLATE == 1) break;
         m = fminf(m, fminf(__builtin_fmaf(-2.0f, acc[i][j][2], cnv[i].z), __builtin_fmaf(-2.0f, acc[i][j][3], cnv[i].w)));
       }
       s_red[(wr * 4 + kg) * 256 + (wc * 4 + (j >> 1)) * 32 + 16 * (j & 1) + l15] = gok ? m : 3.4e38f;
     }
-    zero_acc();
+    if (L1R_ABLATE != 1) zero_acc();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's minima are in LDS ...
     __builtin_amdgcn_s_barrier();                         // ... and so are everybody's
     asm volatile("" ::: "memory");
