@@ -34,6 +34,18 @@ namespace somhip {
 #ifndef L1R_ABLATE
 #define L1R_ABLATE 0
 #endif
+#ifndef L1R_SPREAD
+#define L1R_SPREAD 0
+#endif
+#ifndef L1R_LATE
+#define L1R_LATE 3        // waves 4-7 make their requests behind this column of MFMAs
+#endif
+#ifndef L1R_PRIO_LEVEL
+#define L1R_PRIO_LEVEL 1
+#endif
+#ifndef L1R_PRIO
+#define L1R_PRIO 1        // waves 4-7 at s_setprio 1: -5 % (profiles/r03_l1_variants.txt); L1R_SPREAD (one request per column): +4 %
+#endif
 constexpr int L1R_NS = 4;                   // ring slots
 constexpr int L1R_TOT = 2048;               // uint4 per slot: 4 groups x 4 k-blocks x 64 rows + 8 sample tiles x 4 k-blocks x 32
 constexpr int L1R_RED = 16 * 256;           // floats: [4 groups][4 row quarters][256 samples]
@@ -116,17 +128,20 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1r(CbView cb, int d8
   };
   const int dc = CH + (sel * BD_KB + 2 * arr) * 64;
   const int dx = XH + ((2 * sel) * BD_KB + 2 * arr) * 32;             // + t * BD_KB * 32
-  auto issue = [&]() {                                    // the next stage of the flattened (tile, stage) sequence
-    if (is_stage == 0) issue_tile(is_tile);
+  auto issue_piece = [&](int k) {                         // piece k of the next stage of the flattened (tile, stage) sequence
+    if (k == 0 && is_stage == 0) issue_tile(is_tile);
     uint4 *buf = lds + (q_issue & (NS - 1)) * TOT;
     const int kb0 = is_stage * BD_KB;
-    __builtin_amdgcn_global_load_lds((glb_void *)(pc + kb0 * 64), (lds_void *)(buf + dc), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_void *)(pc + (kb0 + 1) * 64), (lds_void *)(buf + dc + 64), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_void *)(px0 + kb0 * 32), (lds_void *)(buf + dx), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_void *)(px1 + kb0 * 32), (lds_void *)(buf + dx + BD_KB * 32), 16, 0, 0);
-    q_issue++;
-    if (++is_stage == nstage) { is_stage = 0; is_tile++; }
+    if (k == 0) __builtin_amdgcn_global_load_lds((glb_void *)(pc + kb0 * 64), (lds_void *)(buf + dc), 16, 0, 0);
+    if (k == 1) __builtin_amdgcn_global_load_lds((glb_void *)(pc + (kb0 + 1) * 64), (lds_void *)(buf + dc + 64), 16, 0, 0);
+    if (k == 2) __builtin_amdgcn_global_load_lds((glb_void *)(px0 + kb0 * 32), (lds_void *)(buf + dx), 16, 0, 0);
+    if (k == 3) {
+      __builtin_amdgcn_global_load_lds((glb_void *)(px1 + kb0 * 32), (lds_void *)(buf + dx + BD_KB * 32), 16, 0, 0);
+      q_issue++;
+      if (++is_stage == nstage) { is_stage = 0; is_tile++; }
+    }
   };
+  auto issue = [&]() { issue_piece(0); issue_piece(1); issue_piece(2); issue_piece(3); };
   // ---- the multiplying side ----
   f32x4v acc[4][8];                                       // [16-row block of the group][16-sample block of the wave's 128]
   auto zero_acc = [&]() {
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1r(CbView cb, int d8
     // if both made their four requests now (60 cycles and more each, MI355X_MICROARCH.md) the matrix pipe of their SIMD
     // would stand still for that long -- waves 0 .. 3 make them here, waves 4 .. 7 behind their fourth column of MFMAs,
     // so that each wave's requests go out under its partner's MFMAs
-    if (L1R_ABLATE != 2 && wave < 4) issue();
+    if (L1R_ABLATE != 2 && !L1R_SPREAD && wave < 4) issue();
     const uint32_t slot_b = static_cast<uint32_t>((q + 1) & (NS - 1)) * (TOT * 16u);
     const uint32_t nab = fa_b + slot_b, nb = fb_b + slot_b;
     // b0 .. b3 and a0 .. a3 of stage q are back once at most the four reads behind them (b4 .. b7) are outstanding
@@ -176,17 +191,26 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1r(CbView cb, int d8
     // fragments of stage q + 1 while the MFMAs of stage q issue: behind column j of the MFMAs (4 of them) the sample
     // fragment of that column is refilled in place, and -- behind the first four columns -- one code fragment goes into
     // the other set (sched_barrier: the order written here is the order issued)
-    L1R_COL(0); L1R_COL(1); L1R_COL(2); L1R_COL(3);
-    if (L1R_ABLATE != 2 && wave >= 4) issue();
+    // (L1R_SPREAD: one request behind each of a wave's columns 0-3 (waves 0-3) / 4-7 (waves 4-7) instead of four in a row)
+    L1R_COL(0); if (L1R_SPREAD && wave < 4) issue_piece(0);
+    if (L1R_ABLATE != 2 && !L1R_SPREAD && L1R_LATE == 0 && wave >= 4) issue();
+    L1R_COL(1); if (L1R_SPREAD && wave < 4) issue_piece(1);
+    if (L1R_ABLATE != 2 && !L1R_SPREAD && L1R_LATE == 1 && wave >= 4) issue();
+    L1R_COL(2); if (L1R_SPREAD && wave < 4) issue_piece(2);
+    if (L1R_ABLATE != 2 && !L1R_SPREAD && L1R_LATE == 2 && wave >= 4) issue();
+    L1R_COL(3); if (L1R_SPREAD && wave < 4) issue_piece(3);
+    if (L1R_ABLATE != 2 && !L1R_SPREAD && L1R_LATE == 3 && wave >= 4) issue();
     // b4 of stage q: behind it b5 b6 b7 and the eight reads just made
     asm volatile("s_waitcnt lgkmcnt(11)" : "+v"(bfr[4]));
-    L1R_COL(4);
+    L1R_COL(4); if (L1R_SPREAD && wave >= 4) issue_piece(0);
     asm volatile("s_waitcnt lgkmcnt(11)" : "+v"(bfr[5]));  // b6 b7 + 9
-    L1R_COL(5);
+    L1R_COL(5); if (L1R_SPREAD && wave >= 4) issue_piece(1);
+    if (L1R_ABLATE != 2 && !L1R_SPREAD && L1R_LATE == 5 && wave >= 4) issue();
     asm volatile("s_waitcnt lgkmcnt(11)" : "+v"(bfr[6]));  // b7 + 10
-    L1R_COL(6);
+    L1R_COL(6); if (L1R_SPREAD && wave >= 4) issue_piece(2);
+    if (L1R_ABLATE != 2 && !L1R_SPREAD && L1R_LATE == 6 && wave >= 4) issue();
     asm volatile("s_waitcnt lgkmcnt(11)" : "+v"(bfr[7]));  // 11
-    L1R_COL(7);
+    L1R_COL(7); if (L1R_SPREAD && wave >= 4) issue_piece(3);
     q++;
   };
   zero_acc();
@@ -205,6 +229,7 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1r(CbView cb, int d8
   }
   // from here on: stage() waits for stage q + 1, requests stage q + 3 into the slot stage q - 1 was read from, and
   // reads stage q + 1 while it multiplies stage q: two stages in flight, one being read, one just read
+  if (L1R_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(L1R_PRIO_LEVEL);   // (MI355X_MICROARCH.md, two waves per SIMD, item 4: static priority for the younger half)
   float run_min = 3.4e38f;                                // (threads 0 .. 255) minimum over this workgroup's tiles of sample column run_st0
   int64_t run_st0 = -1;
   for (int t = 0; t < my_tiles; t++) {
