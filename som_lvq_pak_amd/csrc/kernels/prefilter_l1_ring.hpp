@@ -38,10 +38,10 @@ namespace somhip {
 #define L1R_SPREAD 0
 #endif
 #ifndef L1R_LATE
-#define L1R_LATE 3        // waves 4-7 make their requests behind this column of MFMAs
+#define L1R_LATE 5        // waves 4-7 make their requests behind this column of MFMAs (3: +1.5 %, profiles/r03_l1_variants.txt)
 #endif
 #ifndef L1R_PRIO_LEVEL
-#define L1R_PRIO_LEVEL 1
+#define L1R_PRIO_LEVEL 3
 #endif
 #ifndef L1R_PRIO
 #define L1R_PRIO 1        // waves 4-7 at s_setprio 1: -5 % (profiles/r03_l1_variants.txt); L1R_SPREAD (one request per column): +4 %
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(512, 2) void k_dist_mfma_bf16_l1r(CbView cb, int d8
     asm volatile("" ::: "memory");
     // stage q + 3 into slot (q + 3) % NS = (q - 1) % NS.  The two waves of a SIMD (w and w + 4) leave the barrier together:
     // if both made their four requests now (60 cycles and more each, MI355X_MICROARCH.md) the matrix pipe of their SIMD
-    // would stand still for that long -- waves 0 .. 3 make them here, waves 4 .. 7 behind their fourth column of MFMAs,
-    // so that each wave's requests go out under its partner's MFMAs
+    // would stand still for that long -- waves 0 .. 3 make them here, waves 4 .. 7 behind a later column of their MFMAs,
+    // so that each wave's requests go out under its partner's MFMAs (L1R_LATE: behind the sixth column measured best)
     if (L1R_ABLATE != 2 && !L1R_SPREAD && wave < 4) issue();
     const uint32_t slot_b = static_cast<uint32_t>((q + 1) & (NS - 1)) * (TOT * 16u);
     const uint32_t nab = fa_b + slot_b, nb = fb_b + slot_b;
