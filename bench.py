@@ -163,8 +163,14 @@ def launch_ranks(a, argv):
     cmd = launcher_command(argv, a.gpus, free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     print("bench.py: starting %d ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
-    child = subprocess.Popen(cmd, env=env)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     try:
+        for line in child.stdout:                        # rank 0's JSON line to stdout; whatever else the ranks' libraries
+            if line.lstrip().startswith("{"):            # print there (gloo's connection notes) to stderr: ONE line on stdout
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(line)
         rc = child.wait()
     except KeyboardInterrupt:
         child.terminate()
