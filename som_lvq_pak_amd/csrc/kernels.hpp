@@ -20,6 +20,7 @@
 // so this umbrella only needs the last one.  K-numbers in comments and in DESIGN.md refer to the
 // section banners inside those files.
 #include "kernels/common.hpp"
+#include "kernels/gauss_rate.hpp"
 #include "kernels/layout.hpp"
 #include "kernels/scan_exact.hpp"
 #include "kernels/prefilter_mfma.hpp"

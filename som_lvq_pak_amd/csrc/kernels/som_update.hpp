@@ -715,7 +715,13 @@ typedef const __attribute__((address_space(4))) u32x4_t konst_u32x4;
 typedef int i32x2_t __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) i32x2_t konst_i32x2;
 
-template <int QW>
+__device__ __forceinline__ double k4g_readlane(double v, uint32_t l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), static_cast<int>(l));
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), static_cast<int>(l));
+  return __hiloint2double(hi, lo);
+}
+
+template <int QW, bool FAST = true>      // FAST false: every rate by the library chain (the A/B switch SOMHIP_GAUSS_LIBM=1)
 __global__ __launch_bounds__(1024) void k_som_update_gauss_s(CbView cb, const float *__restrict__ rows,
                                                              int64_t n_rows, int64_t data_first, int64_t count,
                                                              const int2 *__restrict__ bxy,
@@ -768,11 +774,20 @@ __global__ __launch_bounds__(1024) void k_som_update_gauss_s(CbView cb, const fl
   auto tile_top = [&](uint32_t k) {                    // rates of entries [k, k + TB): two (or more) entries per wave
     const uint32_t tb = n_ent - k < TB ? n_ent - k : TB;
     const int buf = (k / TB) & 1;
+    // 2 radius^2 and its reciprocal once per entry (lane l: entry k + l), handed out with v_readlane; the rate
+    // itself in gauss_rate.hpp's short form, the library chain for the rare argument that form leaves open
+    double den_l = 1.0, rcp_l = 1.0;
+    if (static_cast<uint32_t>(lane) < tb) gauss_rate_den(sc[list[k + lane].sample].thresh, &den_l, &rcp_l);
     for (uint32_t i = wave; i < tb; i += nw) {
       const u32x4_t e = reinterpret_cast<konst_u32x4 *>((const __attribute__((address_space(4))) MemberEntry *)list)[k + i];
       const u32x4_t s = ((konst_u32x4 *)sc)[e.x];      // {alpha, thresh (= radius), fixed, reach}
       const i32x2_t w = ((konst_i32x2 *)bxy)[e.x];
-      s_ga[buf][i][lane] = gaussian_alpha(lattice_sq(cb.topol, w.x, w.y, tx, ty), __uint_as_float(s.y), __uint_as_float(s.x));
+      const double den = k4g_readlane(den_l, i), rcp = k4g_readlane(rcp_l, i);
+      const float lat = lattice_sq(cb.topol, w.x, w.y, tx, ty);
+      float h, a;
+      if (FAST && gauss_rate_fast(lat, den, rcp, &h)) a = __fmul_rn(__uint_as_float(s.x), h);
+      else a = gaussian_alpha(lat, __uint_as_float(s.y), __uint_as_float(s.x));
+      s_ga[buf][i][lane] = a;
     }
     __syncthreads();
   };
@@ -819,5 +834,192 @@ __global__ __launch_bounds__(1024) void k_som_update_gauss_s(CbView cb, const fl
 #pragma unroll
   for (int j = 0; j < QW; j++) *tile_ptr_w(cb, g, q0 + j, lane) = c[j];
 }
+
+// =====================================================================================
+// K4h: K4g for runs that lie in one piece in the data set (no wrap inside the batch, the batch smaller than 4 GiB).
+// K4g costs the CU's ONE scalar unit ~36 instructions per (wave, entry) -- list entry, clamped index, 64-bit row
+// address, tile tests, four branches -- against 24 packed vector instructions: with 32 waves on a CU the scalar unit
+// is the bound (36 x 32 = 1152 issue cycles per round of entries against 768 of vector work per SIMD).  Here:
+//   * a wave holds 32 dims of its 64 rows (8 chunks) and applies an entry in two halves of 16 dims, each with its own
+//     16-SGPR operand buffer: the half being applied and the half in flight -- 48 vector instructions per entry;
+//   * a tile's 32 sample indices come with ONE vector load, lane l = entry l, and reach
+//     the scalar side by v_readlane; the row address is base + index * row bytes in 32 bits;
+//   * no list entry, no mask: under the gaussian neighbourhood every listed sample teaches every live row, so the
+//     dead rows of a last, partial group just compute along and are not stored;
+//   * rates two tiles deep in LDS: the tile being applied and the one being written (K4g: written, barrier, applied --
+//     every wave waits for the slowest rate), one barrier per tile, no test inside a tile: 2 entries per loop trip; a
+//     last partial tile goes entry by entry without look-ahead;
+//   * the scalars of a tile's entries (rate, radius, winner) by vector loads, lane l = entry l, handed to the two
+//     entries a wave computes the rates of by v_readlane.
+// ~12 scalar instructions per (wave, entry).  Bits: the same three roundings per element in the same order.
+// =====================================================================================
+// (a call, not inlined: the library chain wants ~40 registers of its own, which a wave of 8 per SIMD does not have next to
+// its 32 of row data -- around the rare call they go to scratch)
+__device__ __attribute__((noinline)) float gaussian_alpha_call(float lat_sq, float radius, float alpha) {
+  return gaussian_alpha(lat_sq, radius, alpha);
+}
+struct K4hX {                                              // 16 dims of a sample's row as scalar operands
+  f32x16_t v;
+  __device__ __forceinline__ void load(const float *p) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p)); }
+  __device__ __forceinline__ void load_40(const float *p) { asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(v) : "s"(p)); }
+  __device__ __forceinline__ void wait() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); }
+  __device__ __forceinline__ void wait(float &a) { wait(); asm volatile("" : "+v"(a)); }
+  __device__ __forceinline__ float4 chunk(int j) const { return make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]); }
+};
+
+template <bool FAST = true>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_som_update_gauss_h(CbView cb, const float *__restrict__ xrun, int64_t count,
+                                                             const int2 *__restrict__ bxy,
+                                                             const StepScalars *__restrict__ sc,
+                                                             const uint32_t *__restrict__ cnt,
+                                                             const MemberEntry *__restrict__ ent,
+                                                             const uint32_t *__restrict__ order) {
+  constexpr int TB = 32, QW = 8;
+  __shared__ float s_ga[2 * TB][WAVE];
+  const int nw = static_cast<int>(blockDim.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t nslices = static_cast<uint32_t>(cb.d4 / (QW * nw));          // host: d4 % (QW * nw) == 0
+  const uint32_t total = static_cast<uint32_t>(cb.ngroups) * nslices;
+  const uint32_t blk = blockIdx.x / 256u, pos = blockIdx.x % 256u;
+  const uint32_t bsize = total - blk * 256u < 256u ? total - blk * 256u : 256u;
+  const uint32_t item = blk * 256u + ((blk & 1u) ? bsize - 1u - pos : pos);
+  const uint32_t rank = item / nslices;
+  const int64_t g = order ? order[rank] : rank;
+  const uint32_t n_ent = cnt[g];
+  if (n_ent == 0) return;                              // the whole workgroup
+  const int q0 = static_cast<int>(item % nslices) * QW * nw + wave * QW;
+  int tx, ty;
+  txty_of_row(cb, g * WAVE + lane, tx, ty);
+  const bool live = g * WAVE + lane < cb.n;
+
+  float4 c[QW];
+#pragma unroll
+  for (int j = 0; j < QW; j++) c[j] = *tile_ptr(cb, g, q0 + j, lane);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), once
+
+  const MemberEntry *list = ent + g * list_stride(count);
+  const float *xbase = k4s_uniform(xrun + 4 * q0);
+  const uint32_t rowbytes = static_cast<uint32_t>(cb.d) * 4u;
+  const uint32_t ntiles = (n_ent + TB - 1u) / TB;
+  const uint32_t lds_lane = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) float *)&s_ga[0][lane]));
+
+  // lane l (< TB): the sample of entry t * TB + l
+  auto tile_samples = [&](uint32_t t) -> uint32_t {
+    const uint32_t k = t * TB + static_cast<uint32_t>(lane);
+    return (lane < TB && k < n_ent) ? list[k].sample : 0u;
+  };
+  // rates of tile t into its third of s_ga (smp: tile_samples(t))
+  auto tile_rates = [&](uint32_t t, uint32_t smp) {
+    if (t >= ntiles) return;
+    const uint32_t tb = n_ent - t * TB < TB ? n_ent - t * TB : TB;
+    float alpha_l = 0.f, radius_l = 1.f;
+    int wx_l = 0, wy_l = 0;
+    double den_l = 1.0, rcp_l = 1.0;
+    if (static_cast<uint32_t>(lane) < tb) {
+      const StepScalars s = sc[smp];
+      const int2 w = bxy[smp];
+      alpha_l = s.alpha; radius_l = s.thresh; wx_l = w.x; wy_l = w.y;
+      gauss_rate_den(radius_l, &den_l, &rcp_l);
+    }
+    float *dst = &s_ga[(t & 1u) * TB][lane];
+    for (uint32_t i = wave; i < tb; i += nw) {
+      const int il = static_cast<int>(i);
+      const float alpha = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha_l), il));
+      const int wx = __builtin_amdgcn_readlane(wx_l, il), wy = __builtin_amdgcn_readlane(wy_l, il);
+      const double den = k4g_readlane(den_l, i), rcp = k4g_readlane(rcp_l, i);
+      const float lat = lattice_sq(cb.topol, wx, wy, tx, ty);
+      float h, a;
+      if (FAST && gauss_rate_fast(lat, den, rcp, &h)) a = alpha * h;
+      else a = gaussian_alpha_call(lat, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(radius_l), il)), alpha);
+      dst[i * WAVE] = a;
+    }
+  };
+  auto xptr = [&](uint32_t smp_v, uint32_t l) -> const float * {   // row of the sample lane l of smp_v holds
+    const uint32_t idx = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(smp_v), static_cast<int>(l)));
+    return reinterpret_cast<const float *>(reinterpret_cast<const char *>(xbase) + idx * rowbytes);
+  };
+  auto rate_read = [&](float &a, uint32_t addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(a) : "v"(addr) : "memory"); };
+  auto apply = [&](const K4hX &x, float a, int half) {
+    const f32x2 a2 = {a, a};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float4 xv = x.chunk(j);
+      float4 &cc = c[4 * half + j];
+      f32x2 lo = {cc.x, cc.y}, hi = {cc.z, cc.w};
+      const f32x2 tl = k4s_pk_sub(f32x2{xv.x, xv.y}, lo), th = k4s_pk_sub(f32x2{xv.z, xv.w}, hi);
+      const f32x2 sl = a2 * tl, sh = a2 * th;
+      lo = lo + sl; hi = hi + sh;
+      cc = make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+  };
+
+  K4hX x0, x1;                                            // dims [0, 16) / [16, 32) of the wave's slice
+  float aA = 0.f, aB = 0.f;
+  uint32_t smp_cur = 0u;
+  // step u: (barrier) the rates of tile u are made, tile u - 1 is applied.  Tile u's rates go where tile u - 2's were:
+  // those were read during step u - 1, before the barrier; tile u - 1's were written during step u - 1, before it.
+  for (uint32_t u = 0; u <= ntiles; u++) {
+    if (u > 0u) __syncthreads();
+    const uint32_t smp_new = tile_samples(u);
+    tile_rates(u, smp_new);
+    if (u > 0u) {
+      const uint32_t t = u - 1u;
+      const uint32_t tb = n_ent - t * TB < TB ? n_ent - t * TB : TB;
+      const uint32_t base = lds_lane + (t & 1u) * (TB * WAVE * 4u);
+      if (tb == TB) {
+        const float *p = xptr(smp_cur, 0u);
+        x0.load(p);
+        rate_read(aA, base);
+        // an entry in two halves: half 0 waits for x0 and the rate and sends for half 1; half 1 waits for x1 and sends for
+        // the next entry's half 0 and its rate (the tile's last entry sends for nothing: no request is in flight across the
+        // barrier and the rate computation).  sched_barrier: the vector work of a half stays between the request it
+        // follows and the wait it precedes -- the scheduler otherwise sinks it below the next wait, which then stands
+        // right behind its own request
+#define K4H_HALF0(AC)                                                  \
+        x0.wait(AC);                                                   \
+        x1.load_40(p);                                                 \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        apply(x0, AC, 0);                                              \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        x1.wait();
+#define K4H_ENTRY(AC, AN, E)                                           \
+        K4H_HALF0(AC)                                                  \
+        p = xptr(smp_cur, (E) + 1u);                                   \
+        x0.load(p);                                                    \
+        rate_read(AN, base + ((E) + 1u) * (WAVE * 4u));                \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        apply(x1, AC, 1);                                              \
+        __builtin_amdgcn_sched_barrier(0);
+        for (uint32_t e = 0; e < TB - 2u; e += 2u) {
+          K4H_ENTRY(aA, aB, e)
+          K4H_ENTRY(aB, aA, e + 1u)
+        }
+        K4H_ENTRY(aA, aB, TB - 2u)
+        K4H_HALF0(aB)
+        apply(x1, aB, 1);
+#undef K4H_ENTRY
+#undef K4H_HALF0
+      } else {
+        for (uint32_t e = 0; e < tb; e++) {               // the list's last, partial tile: entry by entry, no look-ahead
+          const float *p = xptr(smp_cur, e);
+          x0.load(p);
+          x1.load_40(p);
+          rate_read(aA, base + e * (WAVE * 4u));
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x0.v), "+s"(x1.v));
+          asm volatile("" : "+v"(aA));
+          apply(x0, aA, 0);
+          apply(x1, aA, 1);
+        }
+      }
+    }
+    smp_cur = smp_new;
+  }
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < QW; j++) *tile_ptr_w(cb, g, q0 + j, lane) = c[j];
+  }
+}
+
 
 }  // namespace somhip

@@ -170,12 +170,12 @@ __global__ __launch_bounds__(256, 2) void k_som_update_gemm(CbView cb, const flo
       const int i = (2 * s + k) & 3;
       if (GAUSS) {
         // gaussian_adapt's rate alpha exp(-dd dd / (2 radius^2)), dd = (float) sqrt(lattice_sq) (som_rout.c:539-542): the
-        // numerator as the reference forms it (a correctly rounded float square root, squared in float); the exponent in
+        // numerator in the reference's form (a float square root -- v_sqrt_f32, 1 ulp --, squared in float); the exponent in
         // base 2 with the coefficient's remainder carried along (t + lo is exact to 2^-32 of the exponent), the
         // exponential by v_exp_f32 (1 ulp) instead of a double exp
         const uint32_t xy = q[4 * i + 2];
         const float lat = lattice_sq_small(cb.topol, static_cast<int>(xy & 0x3FFu), static_cast<int>((xy >> 10) & 0x3FFu), u_tx, u_ty);
-        const float dd = __fsqrt_rn(lat);
+        const float dd = __builtin_amdgcn_sqrtf(lat);   // v_sqrt_f32, 1 ulp
         const float n2 = dd * dd;
         const float chi = __uint_as_float(q[4 * i + 3]);
         const float clo = chi * (static_cast<float>(static_cast<int>(xy << 4) >> 24) * 2.3283064365386963e-10f);

@@ -268,3 +268,22 @@ def test_scalar_update_kernel_reads_nothing_before_its_wait(built, tmp_path):
         for blk in re.split(r"\n\.LBB\w+:", body):
             if "ASMSTART\n\ts_load_dwordx16" in blk:
                 assert blk.index("s_waitcnt lgkmcnt(0)") < blk.index("ASMSTART\n\ts_load_dwordx16"), name
+
+
+def test_gaussian_rate_short_form_gives_the_library_chains_float(tmp_path):
+    """kernels/gauss_rate.hpp (the rate of gaussian_adapt, som_rout.c:539-542, without fp64 library calls), compiled for
+    the host, against sqrt / division / exp as the reference writes them with glibc: every argument the short form
+    decides gives the same float, its quotient is the correctly rounded one, and it decides nearly all of them
+    (lattice distances of maps up to 350 x 400, radii over the whole float range, the schedule's 1 ... 128 densely)"""
+    exe = str(tmp_path / "gauss_rate_check")
+    cmd = ["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "som_lvq_pak_amd", "csrc", "kernels"), "-x", "c",
+           os.path.join(ROOT, "tests", "helpers", "gauss_rate_check.c"), "-o", exe, "-lm"]
+    if " fma " in open("/proc/cpuinfo").read():
+        cmd.insert(1, "-mfma")
+    subprocess.check_call(cmd)
+    for seed in (1, 2):
+        p = subprocess.run([exe, "8000000", str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        m = re.match(r"gauss_rate_check: (\d+) cases, (\d+) decided .* (\d+) wrong floats, (\d+) wrong quotients", p.stdout)
+        assert m and int(m.group(3)) == 0 and int(m.group(4)) == 0, p.stdout
+        assert int(m.group(2)) > 0.98 * int(m.group(1)), p.stdout
