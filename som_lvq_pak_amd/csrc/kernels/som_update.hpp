@@ -721,7 +721,7 @@ __device__ __forceinline__ double k4g_readlane(double v, uint32_t l) {
   return __hiloint2double(hi, lo);
 }
 
-template <int QW, bool FAST = true>      // FAST false: every rate by the library chain (the A/B switch SOMHIP_GAUSS_LIBM=1)
+template <int QW>
 __global__ __launch_bounds__(1024) void k_som_update_gauss_s(CbView cb, const float *__restrict__ rows,
                                                              int64_t n_rows, int64_t data_first, int64_t count,
                                                              const int2 *__restrict__ bxy,
@@ -774,20 +774,11 @@ __global__ __launch_bounds__(1024) void k_som_update_gauss_s(CbView cb, const fl
   auto tile_top = [&](uint32_t k) {                    // rates of entries [k, k + TB): two (or more) entries per wave
     const uint32_t tb = n_ent - k < TB ? n_ent - k : TB;
     const int buf = (k / TB) & 1;
-    // 2 radius^2 and its reciprocal once per entry (lane l: entry k + l), handed out with v_readlane; the rate
-    // itself in gauss_rate.hpp's short form, the library chain for the rare argument that form leaves open
-    double den_l = 1.0, rcp_l = 1.0;
-    if (static_cast<uint32_t>(lane) < tb) gauss_rate_den(sc[list[k + lane].sample].thresh, &den_l, &rcp_l);
     for (uint32_t i = wave; i < tb; i += nw) {
       const u32x4_t e = reinterpret_cast<konst_u32x4 *>((const __attribute__((address_space(4))) MemberEntry *)list)[k + i];
       const u32x4_t s = ((konst_u32x4 *)sc)[e.x];      // {alpha, thresh (= radius), fixed, reach}
       const i32x2_t w = ((konst_i32x2 *)bxy)[e.x];
-      const double den = k4g_readlane(den_l, i), rcp = k4g_readlane(rcp_l, i);
-      const float lat = lattice_sq(cb.topol, w.x, w.y, tx, ty);
-      float h, a;
-      if (FAST && gauss_rate_fast(lat, den, rcp, &h)) a = __fmul_rn(__uint_as_float(s.x), h);
-      else a = gaussian_alpha(lat, __uint_as_float(s.y), __uint_as_float(s.x));
-      s_ga[buf][i][lane] = a;
+      s_ga[buf][i][lane] = gaussian_alpha(lattice_sq(cb.topol, w.x, w.y, tx, ty), __uint_as_float(s.y), __uint_as_float(s.x));
     }
     __syncthreads();
   };
@@ -836,7 +827,8 @@ __global__ __launch_bounds__(1024) void k_som_update_gauss_s(CbView cb, const fl
 }
 
 // =====================================================================================
-// K4h: K4g for runs that lie in one piece in the data set (no wrap inside the batch, the batch smaller than 4 GiB).
+// K4h: K4g for runs that lie in one piece in the data set (no wrap inside the batch, the batch smaller than 4 GiB),
+// dims in whole 32s; the rate in gauss_rate.hpp's short form (FAST false: the library chain, SOMHIP_GAUSS_LIBM=1).
 // K4g costs the CU's ONE scalar unit ~36 instructions per (wave, entry) -- list entry, clamped index, 64-bit row
 // address, tile tests, four branches -- against 24 packed vector instructions: with 32 waves on a CU the scalar unit
 // is the bound (36 x 32 = 1152 issue cycles per round of entries against 768 of vector work per SIMD).  Here:

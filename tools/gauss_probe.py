@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """gauss_probe.py -- the bit-equal gaussian update (k_som_update_gauss_s) at the configs[3] shape: time per batch of
-4096 vectors at several radii: K4g with the library chain for the rate (SOMHIP_GAUSS_LIBM=1, SOMHIP_GAUSS_K4G=1), K4g with
-the short form (kernels/gauss_rate.hpp), K4h (k_som_update_gauss_h); the three codebooks compared bit for bit.
+4096 vectors at several radii: K4g (k_som_update_gauss_s, SOMHIP_GAUSS_K4G=1), K4h (k_som_update_gauss_h) with the library
+chain for the rate (SOMHIP_GAUSS_LIBM=1) and with the short form (kernels/gauss_rate.hpp); the three codebooks compared bit
+for bit.
     python tools/gauss_probe.py [batch]"""
 import os
 import sys
@@ -22,12 +23,12 @@ def main():
     bad = 0
     for radius in (128.0, 40.0, 8.0, 2.0):
         res = {}
-        for mode in ("libm", "short", "k4h"):
+        for mode in ("libm", "short", "k4h"):                # K4g; K4h with the library chain; K4h
             os.environ.pop("SOMHIP_GAUSS_LIBM", None); os.environ.pop("SOMHIP_GAUSS_K4G", None)
             if mode == "libm":
-                os.environ["SOMHIP_GAUSS_LIBM"] = "1"
-            if mode != "k4h":
                 os.environ["SOMHIP_GAUSS_K4G"] = "1"
+            if mode == "short":
+                os.environ["SOMHIP_GAUSS_LIBM"] = "1"
             cb = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_GAUSSIAN, 256, 256)
             E.som_train(cb, ds, 10_000_000, 0.05, radius, batch=B, start_iter=0, count=B, trace=False)   # warm
             eng.timing(True); eng.timing_reset()
@@ -39,7 +40,7 @@ def main():
             cb.close()
         same = all(np.array_equal(res["libm"][0].view(np.uint32), res[m][0].view(np.uint32)) for m in ("short", "k4h"))
         bad += 0 if same else 1
-        print("radius %6.1f batch %d: update kernel %7.3f ms (K4g, library chain) -> %7.3f ms (K4g, short form) -> %7.3f ms (K4h); whole step %7.3f -> %7.3f -> %7.3f ms; codebooks %s" % (
+        print("radius %6.1f batch %d: update kernel %7.3f ms (K4g) -> %7.3f ms (K4h, library chain for the rate) -> %7.3f ms (K4h); whole step %7.3f -> %7.3f -> %7.3f ms; codebooks %s" % (
             radius, B, res["libm"][1], res["short"][1], res["k4h"][1], res["libm"][2], res["short"][2], res["k4h"][2], "bit-equal" if same else "DIFFERENT"), flush=True)
     os.environ.pop("SOMHIP_GAUSS_LIBM", None); os.environ.pop("SOMHIP_GAUSS_K4G", None)
     sys.exit(1 if bad else 0)
