@@ -839,7 +839,7 @@ __global__ __launch_bounds__(1024) void k_som_update_gauss_s(CbView cb, const fl
 //   * no list entry, no mask: under the gaussian neighbourhood every listed sample teaches every live row, so the
 //     dead rows of a last, partial group just compute along and are not stored;
 //   * rates two tiles deep in LDS: the tile being applied and the one being written (K4g: written, barrier, applied --
-//     every wave waits for the slowest rate), one barrier per tile, no test inside a tile: 2 entries per loop trip; a
+//     every wave waits for the slowest rate), one barrier per tile of 64, no test inside a tile: 2 entries per loop trip; a
 //     last partial tile goes entry by entry without look-ahead;
 //   * the scalars of a tile's entries (rate, radius, winner) by vector loads, lane l = entry l, handed to the two
 //     entries a wave computes the rates of by v_readlane.
@@ -866,7 +866,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                                                              const uint32_t *__restrict__ cnt,
                                                              const MemberEntry *__restrict__ ent,
                                                              const uint32_t *__restrict__ order) {
-  constexpr int TB = 32, QW = 8;
+#ifndef K4H_TB
+#define K4H_TB 64            // entries per tile = per barrier (32: 8.19 ms per 4096 vectors at configs[3], 64: 8.00)
+#endif
+  constexpr int TB = K4H_TB, QW = 8;
   __shared__ float s_ga[2 * TB][WAVE];
   const int nw = static_cast<int>(blockDim.x >> 6);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;

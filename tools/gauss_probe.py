@@ -21,7 +21,7 @@ def main():
     lo, hi, cnt = E.column_minmax(ds)
     init = E.randinit_from_bbox(lo, hi, cnt, 256, 256, 7)
     bad = 0
-    for radius in (128.0, 40.0, 8.0, 2.0):
+    for radius in [float(r) for r in os.environ.get("GAUSS_PROBE_RADII", "128,40,8,2").split(",")]:
         res = {}
         for mode in ("libm", "short", "k4h"):                # K4g; K4h with the library chain; K4h
             os.environ.pop("SOMHIP_GAUSS_LIBM", None); os.environ.pop("SOMHIP_GAUSS_K4G", None)
