@@ -230,12 +230,14 @@ __global__ __launch_bounds__(256) void k_topk_select(CbView cb, int64_t count, i
   }
 }
 
-// (2) by row group: one workgroup per group takes the samples filed under it four at a time per wave -- the group's
-// tile (64 rows x d, 256 KiB at d = 1024) is streamed once per four samples instead of once per pair, and the waves
-// of a workgroup read it together.  The distance of every (row, sample) is the reference's sum in the reference's
+// (2) by row group: the samples filed under a group are taken four at a time -- the group's tile (64 rows x d, 256 KiB
+// at d = 1024) is streamed once per four samples instead of once per pair.  One WAVE per workgroup (round 3): a pass
+// keeps its four sample rows in LDS (16 KiB at d = 1024), and as waves of one 256-thread workgroup the passes held 64 KiB
+// each -- two workgroups per CU, three rounds of them at configs[4] where most groups have work for one wave only
+// (270 us per batch of 1024; 25 000 mostly empty workgroups of one wave each: see DESIGN section 4).  The distance of every (row, sample) is the reference's sum in the reference's
 // order, as in k_topk_pairs; the results go to the same per-pair slots, so (3) does not care which of the two ran.
-template <int K>
-__global__ __launch_bounds__(256) void k_topk_pairs_bygroup(CbView cb, const float *__restrict__ rows, int64_t n_rows,
+template <int K, int S = 4>       // S samples per pass over the group's tile
+__global__ __launch_bounds__(64) void k_topk_pairs_bygroup(CbView cb, const float *__restrict__ rows, int64_t n_rows,
                                                             int64_t first, int tie_knn, const uint32_t *__restrict__ gcnt,
                                                             const uint2 *__restrict__ glist, uint32_t cap_g,
                                                             const uint32_t *__restrict__ counter,
@@ -244,28 +246,44 @@ __global__ __launch_bounds__(256) void k_topk_pairs_bygroup(CbView cb, const flo
   const int64_t g = blockIdx.x;
   const uint32_t n = gcnt[g] < cap_g ? gcnt[g] : cap_g;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int64_t row = g * WAVE + lane;
   const uint32_t grow = unit_of_row(cb, row);
-  extern __shared__ float4 s_topk_x[];                     // [wave][4 samples][d4]: the samples' rows of the pass in hand
-  float4 *sx = s_topk_x + static_cast<size_t>(wave) * 4 * cb.d4;
+  extern __shared__ float4 s_topk_x[];                     // [S samples][d4]: the samples' rows of the pass in hand
+  float4 *sx = s_topk_x;
+  const int64_t first0 = first % n_rows;
   constexpr int U = 8;                                   // tile chunks per register buffer (two buffers, as in K3's row stream)
   // (a crowded group -- a class centre draws hundreds of a batch's samples -- is spread over the gridDim.y workgroups of its row)
-  for (uint32_t base = (blockIdx.y * 4u + static_cast<uint32_t>(wave)) * 4u; base < n; base += 16u * gridDim.y) {
-    const uint32_t m = n - base < 4u ? n - base : 4u;
-    uint32_t slot[4];
+  for (uint32_t base = blockIdx.y * static_cast<uint32_t>(S); base < n; base += S * gridDim.y) {
+    const uint32_t m = n - base < static_cast<uint32_t>(S) ? n - base : static_cast<uint32_t>(S);
+    uint32_t slot[S];
+    float4 stage[S][4];                                    // (host: d4 <= 256) all of a pass's row loads go out before the first is waited for
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < S; s++) {
       const uint2 en = glist[static_cast<size_t>(g) * cap_g + base + (static_cast<uint32_t>(s) < m ? s : 0)];
       slot[s] = en.y;
-      const float4 *x = reinterpret_cast<const float4 *>(rows + ((first + en.x) % n_rows) * cb.d);
-      for (int q = lane; q < cb.d4; q += WAVE) sx[s * cb.d4 + q] = x[q];
+      int64_t r = first0 + en.x;
+      if (r >= n_rows) r %= n_rows;                        // (the run wraps inside the data set: rare)
+      const float4 *x = reinterpret_cast<const float4 *>(rows + r * cb.d);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = lane + j * WAVE;
+        stage[s][j] = x[q < cb.d4 ? q : cb.d4 - 1];
+      }
     }
+#pragma unroll
+    for (int s = 0; s < S; s++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = lane + j * WAVE;
+        if (q < cb.d4) sx[s * cb.d4 + q] = stage[s][j];
+      }
     // (each wave reads back only what it wrote: no barrier, the LDS operations of a wave complete in order)
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float acc[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) acc[s] = 0.0f;
     auto chunk = [&](int q, const float4 c) {
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
+      for (int s = 0; s < S; s++) {
         const float4 xs = sx[s * cb.d4 + q];
         acc[s] = sq_acc(acc[s], c.x, xs.x);
         acc[s] = sq_acc(acc[s], c.y, xs.y);
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(256) void k_topk_pairs_bygroup(CbView cb, const flo
     }
     for (int q = nfull; q < cb.d4; q++) chunk(q, *tile_ptr(cb, g, q, lane));
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < S; s++) {
       if (static_cast<uint32_t>(s) >= m) break;
       uint64_t k = row < cb.n ? make_key(acc[s], tie_knn ? ~grow : grow) : KEY_NONE;
 #pragma unroll
