@@ -231,32 +231,52 @@ __global__ __launch_bounds__(256) void k_topk_select(CbView cb, int64_t count, i
 }
 
 // (2) by row group: the samples filed under a group are taken four at a time -- the group's tile (64 rows x d, 256 KiB
-// at d = 1024) is streamed once per four samples instead of once per pair.  One WAVE per workgroup (round 3): a pass
-// keeps its four sample rows in LDS (16 KiB at d = 1024), and as waves of one 256-thread workgroup the passes held 64 KiB
-// each -- two workgroups per CU, three rounds of them at configs[4] where most groups have work for one wave only
-// (270 us per batch of 1024; 25 000 mostly empty workgroups of one wave each: see DESIGN section 4).  The distance of every (row, sample) is the reference's sum in the reference's
+// at d = 1024) is streamed once per four samples instead of once per pair.  One WAVE per workgroup and no LDS (round 3):
+// as waves of one 256-thread workgroup with the sample rows in LDS, the passes held 64 KiB each -- two workgroups per
+// CU, three rounds of them at configs[4], where most groups have work for one wave only (270 us per batch of 1024).  The distance of every (row, sample) is the reference's sum in the reference's
 // order, as in k_topk_pairs; the results go to the same per-pair slots, so (3) does not care which of the two ran.
+// The passes as a list: (group, first sample of the pass) for every S samples filed under a group.  (A grid of
+// groups x passes is mostly empty workgroups -- at configs[4] 1600 of 100 000 had work, and starting the others was
+// what the kernel's 175 us were.)
+template <int S>
+__global__ __launch_bounds__(256) void k_topk_worklist(int64_t ngroups, const uint32_t *__restrict__ gcnt, uint32_t cap_g,
+                                                       const uint32_t *__restrict__ counter, uint32_t *__restrict__ wcount,
+                                                       uint2 *__restrict__ work, uint32_t wcap) {
+  if (counter[1]) return;
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < ngroups; g += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const uint32_t n = gcnt[g] < cap_g ? gcnt[g] : cap_g;
+    const uint32_t np = (n + S - 1u) / S;
+    if (np) {
+      const uint32_t b = atomicAdd(wcount, np);
+      for (uint32_t i = 0; i < np && b + i < wcap; i++) work[b + i] = make_uint2(static_cast<uint32_t>(g), i * S);
+    }
+  }
+}
+
 template <int K, int S = 4>       // S samples per pass over the group's tile
 __global__ __launch_bounds__(64) void k_topk_pairs_bygroup(CbView cb, const float *__restrict__ rows, int64_t n_rows,
                                                             int64_t first, int tie_knn, const uint32_t *__restrict__ gcnt,
                                                             const uint2 *__restrict__ glist, uint32_t cap_g,
                                                             const uint32_t *__restrict__ counter,
+                                                            const uint32_t *__restrict__ wcount, const uint2 *__restrict__ work, uint32_t wcap,
                                                             uint64_t *__restrict__ partial /* [pair][K] */) {
   if (counter[1]) return;
-  const int64_t g = blockIdx.x;
-  const uint32_t n = gcnt[g] < cap_g ? gcnt[g] : cap_g;
+  const uint32_t nwork = *wcount < wcap ? *wcount : wcap;
   const int lane = threadIdx.x & 63;
-  const int64_t row = g * WAVE + lane;
-  const uint32_t grow = unit_of_row(cb, row);
-  extern __shared__ float4 s_topk_x[];                     // [S samples][d4]: the samples' rows of the pass in hand
-  float4 *sx = s_topk_x;
   const int64_t first0 = first % n_rows;
   constexpr int U = 8;                                   // tile chunks per register buffer (two buffers, as in K3's row stream)
-  // (a crowded group -- a class centre draws hundreds of a batch's samples -- is spread over the gridDim.y workgroups of its row)
-  for (uint32_t base = blockIdx.y * static_cast<uint32_t>(S); base < n; base += S * gridDim.y) {
+  for (uint32_t w = blockIdx.x; w < nwork; w += gridDim.x) {
+    const int64_t g = work[w].x;
+    const uint32_t base = work[w].y;
+    const uint32_t n = gcnt[g] < cap_g ? gcnt[g] : cap_g;
+    const int64_t row = g * WAVE + lane;
+    const uint32_t grow = unit_of_row(cb, row);
     const uint32_t m = n - base < static_cast<uint32_t>(S) ? n - base : static_cast<uint32_t>(S);
     uint32_t slot[S];
-    float4 stage[S][4];                                    // (host: d4 <= 256) all of a pass's row loads go out before the first is waited for
+    // the pass's sample rows stay in REGISTERS, lane l of xs[s][j] = chunk 64 j + l of sample s (host: d4 <= 256), and a
+    // chunk's four floats reach the arithmetic as scalar operands by v_readlane: through LDS (the first form) every chunk
+    // cost the lone wave four exposed ds_read latencies
+    float4 xs[S][4];
 #pragma unroll
     for (int s = 0; s < S; s++) {
       const uint2 en = glist[static_cast<size_t>(g) * cap_g + base + (static_cast<uint32_t>(s) < m ? s : 0)];
@@ -267,47 +287,57 @@ __global__ __launch_bounds__(64) void k_topk_pairs_bygroup(CbView cb, const floa
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int q = lane + j * WAVE;
-        stage[s][j] = x[q < cb.d4 ? q : cb.d4 - 1];
+        xs[s][j] = x[q < cb.d4 ? q : cb.d4 - 1];
       }
     }
-#pragma unroll
-    for (int s = 0; s < S; s++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int q = lane + j * WAVE;
-        if (q < cb.d4) sx[s * cb.d4 + q] = stage[s][j];
-      }
-    // (each wave reads back only what it wrote: no barrier, the LDS operations of a wave complete in order)
     float acc[S];
 #pragma unroll
     for (int s = 0; s < S; s++) acc[s] = 0.0f;
-    auto chunk = [&](int q, const float4 c) {
+    auto bcast = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+    auto chunk = [&](auto jc, int q, const float4 c) {     // jc: the chunk's block of 64 as a compile-time constant
+      constexpr int j = decltype(jc)::value;
+      const int l = q - 64 * j;
+      // a lone wave per SIMD: written so that the 4 S squares of a chunk are independent of one another and the S sums advance
+      // side by side (sample after sample, every instruction waited for the one before it: 900 cycles per chunk);
+      // each sum still takes its dims in order, one rounding per operation (sq_acc's arithmetic)
+      float sq[S][4];
 #pragma unroll
       for (int s = 0; s < S; s++) {
-        const float4 xs = sx[s * cb.d4 + q];
-        acc[s] = sq_acc(acc[s], c.x, xs.x);
-        acc[s] = sq_acc(acc[s], c.y, xs.y);
-        acc[s] = sq_acc(acc[s], c.z, xs.z);
-        acc[s] = sq_acc(acc[s], c.w, xs.w);
+        const float d0 = c.x - bcast(xs[s][j].x, l), d1 = c.y - bcast(xs[s][j].y, l);
+        const float d2 = c.z - bcast(xs[s][j].z, l), d3 = c.w - bcast(xs[s][j].w, l);
+        sq[s][0] = d0 * d0; sq[s][1] = d1 * d1; sq[s][2] = d2 * d2; sq[s][3] = d3 * d3;
       }
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int s = 0; s < S; s++) acc[s] = acc[s] + sq[s][e];
     };
     float4 bufA[U], bufB[U];
     const int nfull = (cb.d4 / (2 * U)) * (2 * U), last = cb.d4 - 1;
     if (nfull > 0) {
 #pragma unroll
       for (int u = 0; u < U; u++) bufA[u] = *tile_ptr(cb, g, u, lane);
-      for (int qb = 0; qb < nfull; qb += 2 * U) {
+    }
+    auto block = [&](auto jc) {                            // chunks [64 j, 64 j + 64) of the rows
+      constexpr int j = decltype(jc)::value;
+      const int q_hi = cb.d4 < 64 * j + 64 ? cb.d4 : 64 * j + 64;
+      const int full_hi = nfull < q_hi ? nfull : q_hi;     // (2 U divides 64: a double step never straddles two blocks)
+      for (int qb = 64 * j; qb < full_hi; qb += 2 * U) {
 #pragma unroll
         for (int u = 0; u < U; u++) bufB[u] = *tile_ptr(cb, g, qb + U + u, lane);
 #pragma unroll
-        for (int u = 0; u < U; u++) chunk(qb + u, bufA[u]);
+        for (int u = 0; u < U; u++) chunk(jc, qb + u, bufA[u]);
 #pragma unroll
         for (int u = 0; u < U; u++) { const int q = qb + 2 * U + u; bufA[u] = *tile_ptr(cb, g, q < last ? q : last, lane); }
 #pragma unroll
-        for (int u = 0; u < U; u++) chunk(qb + U + u, bufB[u]);
+        for (int u = 0; u < U; u++) chunk(jc, qb + U + u, bufB[u]);
       }
-    }
-    for (int q = nfull; q < cb.d4; q++) chunk(q, *tile_ptr(cb, g, q, lane));
+      for (int q = full_hi > 64 * j ? full_hi : 64 * j; q < q_hi; q++) chunk(jc, q, *tile_ptr(cb, g, q, lane));
+    };
+    block(std::integral_constant<int, 0>());
+    if (cb.d4 > 64) block(std::integral_constant<int, 1>());
+    if (cb.d4 > 128) block(std::integral_constant<int, 2>());
+    if (cb.d4 > 192) block(std::integral_constant<int, 3>());
 #pragma unroll
     for (int s = 0; s < S; s++) {
       if (static_cast<uint32_t>(s) >= m) break;
