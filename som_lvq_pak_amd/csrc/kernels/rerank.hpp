@@ -162,79 +162,98 @@ __global__ __launch_bounds__(256) void k_rerank_topk(CbView cb, const float *__r
 // pairs' keys.  A full list (*overflow != 0) sends the run to the one-wave kernel instead.
 struct TopkSpan { uint32_t start, n; };
 
+// (round 3: workgroup = 32 samples x 32 slices of the groups, as k_group_kth -- one wave per sample with lane = group
+// read wmin across its rows, a cache line per lane, three times: 51 us at configs[4].)
 template <int K>
-__global__ __launch_bounds__(256) void k_topk_select(CbView cb, int64_t count, int64_t bpad,
-                                                     const float *__restrict__ wmin,
-                                                     const float *__restrict__ tau, uint32_t cap,
-                                                     uint2 *__restrict__ pairs, TopkSpan *__restrict__ span,
-                                                     uint32_t *__restrict__ counter /* [0] fill, [1] overflow */,
-                                                     uint32_t *__restrict__ gcnt = nullptr, uint2 *__restrict__ glist = nullptr,
-                                                     uint32_t cap_g = 0) {
-  const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (b >= count) return;
+__global__ __launch_bounds__(1024) void k_topk_select(CbView cb, int64_t count, int64_t bpad,
+                                                      const float *__restrict__ wmin,
+                                                      const float *__restrict__ tau, uint32_t cap,
+                                                      uint2 *__restrict__ pairs, TopkSpan *__restrict__ span,
+                                                      uint32_t *__restrict__ counter /* [0] fill, [1] overflow */,
+                                                      uint32_t *__restrict__ gcnt = nullptr, uint2 *__restrict__ glist = nullptr,
+                                                      uint32_t cap_g = 0) {
+  __shared__ float s_k[32][K][32];
+  __shared__ uint32_t s_n[32][32];
+  __shared__ uint32_t s_start[32], s_total[32];
+  __shared__ float s_thr[32];
+  const int tid = threadIdx.x, bx = tid & 31, gy = tid >> 5;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * 32 + bx;
+  const bool valid = b < count;
   float mine[K];
 #pragma unroll
   for (int t = 0; t < K; t++) mine[t] = 3.4e38f;
-  for (int64_t g = lane; g < cb.ngroups; g += WAVE) {
-    float v = wmin[g * bpad + b];
+  auto insert = [&](float v) {                             // sorted insertion
 #pragma unroll
     for (int t = 0; t < K; t++) {
       const float lo = fminf(mine[t], v);
       v = fmaxf(mine[t], v);
       mine[t] = lo;
     }
-  }
-  float mk = 3.4e38f;
-  for (int t = 0; t < K; t++) {
-    float h = mine[0];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) h = fminf(h, __shfl_xor(h, off, WAVE));
-    mk = h;
-    const unsigned long long who = __ballot(mine[0] == h);
-    if (lane == __builtin_ctzll(who)) {
-#pragma unroll
-      for (int u = 0; u + 1 < K; u++) mine[u] = mine[u + 1];
-      mine[K - 1] = 3.4e38f;
+  };
+  if (valid) {
+    int64_t g = gy;
+    for (; g + 96 < cb.ngroups; g += 128) {
+      const float v0 = wmin[g * bpad + b], v1 = wmin[(g + 32) * bpad + b], v2 = wmin[(g + 64) * bpad + b], v3 = wmin[(g + 96) * bpad + b];
+      insert(v0); insert(v1); insert(v2); insert(v3);
     }
+    for (; g < cb.ngroups; g += 32) insert(wmin[g * bpad + b]);
   }
-  const float thr = (mk >= 3.0e38f) ? 3.4e38f : mk + tau[b];
-  uint32_t total = 0;
-  for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
-    const int64_t gl = gb + lane;
-    total += __popcll(__ballot(gl < cb.ngroups && wmin[gl * bpad + b] <= thr));
+#pragma unroll
+  for (int t = 0; t < K; t++) s_k[gy][t][bx] = mine[t];
+  __syncthreads();
+  if (gy < 4) {
+    for (int k = gy + 4; k < 32; k += 4)
+#pragma unroll
+      for (int u = 0; u < K; u++) insert(s_k[k][u][bx]);
+#pragma unroll
+    for (int t = 0; t < K; t++) s_k[gy][t][bx] = mine[t];      // (slices 0-3 are read by nobody but slice 0, below)
   }
-  uint32_t start = 0;
-  if (lane == 0) {
-    start = atomicAdd(counter, total);
+  __syncthreads();
+  if (gy == 0) {
+    for (int k = 1; k < 4; k++)
+#pragma unroll
+      for (int u = 0; u < K; u++) insert(s_k[k][u][bx]);
+    const float mk = mine[K - 1];
+    s_thr[bx] = (mk >= 3.0e38f || !valid) ? 3.4e38f : mk + tau[b];
+  }
+  __syncthreads();
+  const float thr = s_thr[bx];
+  uint32_t n = 0;
+  if (valid)
+    for (int64_t g = gy; g < cb.ngroups; g += 32) n += wmin[g * bpad + b] <= thr ? 1u : 0u;
+  s_n[gy][bx] = n;
+  __syncthreads();
+  if (gy == 0 && valid) {
+    uint32_t total = 0;
+    for (int k = 0; k < 32; k++) total += s_n[k][bx];
+    const uint32_t start = atomicAdd(counter, total);
     if (start + total > cap) atomicMax(counter + 1, 1u);
     span[b].start = start; span[b].n = total;
+    s_start[bx] = start; s_total[bx] = total;
   }
-  start = __shfl(start, 0, WAVE);
-  if (start + total > cap) return;
-  uint32_t at = start;
-  for (int64_t gb = 0; gb < cb.ngroups; gb += WAVE) {
-    const int64_t gl = gb + lane;
-    const bool q = gl < cb.ngroups && wmin[gl * bpad + b] <= thr;
-    const unsigned long long ball = __ballot(q);
-    if (q) {
-      const uint32_t p = at + __popcll(ball & ((1ull << lane) - 1));
-      pairs[p] = make_uint2(static_cast<uint32_t>(b), static_cast<uint32_t>(gl));
-      if (gcnt) {                                        // the same pair filed under its group (k_topk_pairs_bygroup)
-        const uint32_t slot = atomicAdd(&gcnt[gl], 1u);
-        if (slot < cap_g) glist[static_cast<size_t>(gl) * cap_g + slot] = make_uint2(static_cast<uint32_t>(b), p);
+  __syncthreads();
+  if (!valid || s_start[bx] + s_total[bx] > cap) return;
+  uint32_t at = s_start[bx];
+  for (int k = 0; k < gy; k++) at += s_n[k][bx];
+  for (int64_t g = gy; g < cb.ngroups; g += 32) {
+    if (wmin[g * bpad + b] <= thr) {
+      const uint32_t p = at++;
+      pairs[p] = make_uint2(static_cast<uint32_t>(b), static_cast<uint32_t>(g));
+      if (gcnt) {                                          // the same pair filed under its group (k_topk_pairs_bygroup)
+        const uint32_t slot = atomicAdd(&gcnt[g], 1u);
+        if (slot < cap_g) glist[static_cast<size_t>(g) * cap_g + slot] = make_uint2(static_cast<uint32_t>(b), p);
         else atomicMax(counter + 1, 1u);
       }
     }
-    at += __popcll(ball);
   }
 }
 
 // (2) by row group: the samples filed under a group are taken four at a time -- the group's tile (64 rows x d, 256 KiB
 // at d = 1024) is streamed once per four samples instead of once per pair.  One WAVE per workgroup and no LDS (round 3):
 // as waves of one 256-thread workgroup with the sample rows in LDS, the passes held 64 KiB each -- two workgroups per
-// CU, three rounds of them at configs[4], where most groups have work for one wave only (270 us per batch of 1024).  The distance of every (row, sample) is the reference's sum in the reference's
-// order, as in k_topk_pairs; the results go to the same per-pair slots, so (3) does not care which of the two ran.
+// CU, three rounds of them at configs[4], where most groups have work for one wave only (270 us per batch of 1024).
+// The distance of every (row, sample) is the reference's sum in the reference's order, as in k_topk_pairs; the results go
+// to the same per-pair slots, so (3) does not care which of the two ran.
 // The passes as a list: (group, first sample of the pass) for every S samples filed under a group.  (A grid of
 // groups x passes is mostly empty workgroups -- at configs[4] 1600 of 100 000 had work, and starting the others was
 // what the kernel's 175 us were.)
@@ -472,42 +491,53 @@ __global__ __launch_bounds__(256) void k_group_min(int64_t ngroups, int64_t bpad
 
 // The K-th smallest group minimum per sample (same output convention as k_group_min: the ordered image of the
 // float): the two-level pre-filter of a top-K search measures its level-1 window from this value instead of the
-// minimum.  Workgroup = 32 samples x 8 slices of the groups (coalesced over samples); each thread keeps the K
-// smallest of its slice, thread (sample, slice 0) merges the eight lists.  Fewer than K groups: 3.4e38 (all pass).
+// minimum.  Workgroup = 32 samples x 32 slices of the groups (coalesced over samples); each thread keeps the K
+// smallest of its slice; the lists are merged in two steps.  Fewer than K groups: 3.4e38 (all pass).
 template <int K>
-__global__ __launch_bounds__(256) void k_group_kth(int64_t ngroups, int64_t bpad, const float *__restrict__ wmin,
-                                                   uint32_t *__restrict__ gkth) {
-  __shared__ float s_k[8][K][32];
+__global__ __launch_bounds__(1024) void k_group_kth(int64_t ngroups, int64_t bpad, const float *__restrict__ wmin,
+                                                    uint32_t *__restrict__ gkth) {
+  // 32 samples x 32 slices of the groups (round 3; 8 slices of 256 threads: 195 dependent trips per thread at
+  // configs[4], 74 us on 32 workgroups); the slices' lists are merged 8 -> 1 by four threads per sample, then 4 -> 1
+  __shared__ float s_k[32][K][32];
   const int tid = threadIdx.x, bx = tid & 31, gy = tid >> 5;
   const int64_t b = static_cast<int64_t>(blockIdx.x) * 32 + bx;
   float mine[K];
 #pragma unroll
   for (int t = 0; t < K; t++) mine[t] = 3.4e38f;
-  if (b < bpad)
-    for (int64_t g = gy; g < ngroups; g += 8) {
-      float v = wmin[g * bpad + b];
+  auto insert = [&](float v) {                             // sorted insertion
 #pragma unroll
-      for (int t = 0; t < K; t++) {                      // sorted insertion
-        const float lo = fminf(mine[t], v);
-        v = fmaxf(mine[t], v);
-        mine[t] = lo;
-      }
+    for (int t = 0; t < K; t++) {
+      const float lo = fminf(mine[t], v);
+      v = fmaxf(mine[t], v);
+      mine[t] = lo;
     }
+  };
+  if (b < bpad) {
+    int64_t g = gy;
+    for (; g + 96 < ngroups; g += 128) {                   // four loads in flight
+      const float v0 = wmin[g * bpad + b], v1 = wmin[(g + 32) * bpad + b], v2 = wmin[(g + 64) * bpad + b], v3 = wmin[(g + 96) * bpad + b];
+      insert(v0); insert(v1); insert(v2); insert(v3);
+    }
+    for (; g < ngroups; g += 32) insert(wmin[g * bpad + b]);
+  }
 #pragma unroll
   for (int t = 0; t < K; t++) s_k[gy][t][bx] = mine[t];
   __syncthreads();
+  if (gy < 4) {
+    for (int k = gy + 4; k < 32; k += 4)
+#pragma unroll
+      for (int u = 0; u < K; u++) insert(s_k[k][u][bx]);
+  }
+  __syncthreads();                                         // (everyone has read what it merges before the four write)
+  if (gy < 4) {
+#pragma unroll
+    for (int t = 0; t < K; t++) s_k[gy][t][bx] = mine[t];
+  }
+  __syncthreads();
   if (gy == 0 && b < bpad) {
-    for (int k = 1; k < 8; k++)
+    for (int k = 1; k < 4; k++)
 #pragma unroll
-      for (int u = 0; u < K; u++) {
-        float v = s_k[k][u][bx];
-#pragma unroll
-        for (int t = 0; t < K; t++) {
-          const float lo = fminf(mine[t], v);
-          v = fmaxf(mine[t], v);
-          mine[t] = lo;
-        }
-      }
+      for (int u = 0; u < K; u++) insert(s_k[k][u][bx]);
     gkth[b] = float_to_ordered(mine[K - 1]);
   }
 }
