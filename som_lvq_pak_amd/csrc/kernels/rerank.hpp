@@ -162,8 +162,9 @@ __global__ __launch_bounds__(256) void k_rerank_topk(CbView cb, const float *__r
 // pairs' keys.  A full list (*overflow != 0) sends the run to the one-wave kernel instead.
 struct TopkSpan { uint32_t start, n; };
 
-// (round 3: workgroup = 32 samples x 32 slices of the groups, as k_group_kth -- one wave per sample with lane = group
-// read wmin across its rows, a cache line per lane, three times: 51 us at configs[4].)
+// (round 3: workgroup = TOPK_NB samples x TOPK_NS slices of the groups, as k_group_kth -- one wave per sample with
+// lane = group read wmin across its rows, a cache line per lane, three times: 51 us at configs[4].)
+constexpr int TOPK_NB = 16, TOPK_NS = 1024 / TOPK_NB;
 template <int K>
 __global__ __launch_bounds__(1024) void k_topk_select(CbView cb, int64_t count, int64_t bpad,
                                                       const float *__restrict__ wmin,
@@ -172,12 +173,13 @@ __global__ __launch_bounds__(1024) void k_topk_select(CbView cb, int64_t count, 
                                                       uint32_t *__restrict__ counter /* [0] fill, [1] overflow */,
                                                       uint32_t *__restrict__ gcnt = nullptr, uint2 *__restrict__ glist = nullptr,
                                                       uint32_t cap_g = 0) {
-  __shared__ float s_k[32][K][32];
-  __shared__ uint32_t s_n[32][32];
-  __shared__ uint32_t s_start[32], s_total[32];
-  __shared__ float s_thr[32];
-  const int tid = threadIdx.x, bx = tid & 31, gy = tid >> 5;
-  const int64_t b = static_cast<int64_t>(blockIdx.x) * 32 + bx;
+  constexpr int NB = TOPK_NB, NS = TOPK_NS;
+  __shared__ float s_k[NS][K][NB];
+  __shared__ uint32_t s_n[NS][NB];
+  __shared__ uint32_t s_start[NB], s_total[NB];
+  __shared__ float s_thr[NB];
+  const int tid = threadIdx.x, bx = tid % NB, gy = tid / NB;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * NB + bx;
   const bool valid = b < count;
   float mine[K];
 #pragma unroll
@@ -192,25 +194,25 @@ __global__ __launch_bounds__(1024) void k_topk_select(CbView cb, int64_t count, 
   };
   if (valid) {
     int64_t g = gy;
-    for (; g + 96 < cb.ngroups; g += 128) {
-      const float v0 = wmin[g * bpad + b], v1 = wmin[(g + 32) * bpad + b], v2 = wmin[(g + 64) * bpad + b], v3 = wmin[(g + 96) * bpad + b];
+    for (; g + 3 * NS < cb.ngroups; g += 4 * NS) {
+      const float v0 = wmin[g * bpad + b], v1 = wmin[(g + NS) * bpad + b], v2 = wmin[(g + 2 * NS) * bpad + b], v3 = wmin[(g + 3 * NS) * bpad + b];
       insert(v0); insert(v1); insert(v2); insert(v3);
     }
-    for (; g < cb.ngroups; g += 32) insert(wmin[g * bpad + b]);
+    for (; g < cb.ngroups; g += NS) insert(wmin[g * bpad + b]);
   }
 #pragma unroll
   for (int t = 0; t < K; t++) s_k[gy][t][bx] = mine[t];
   __syncthreads();
-  if (gy < 4) {
-    for (int k = gy + 4; k < 32; k += 4)
+  if (gy < 8) {
+    for (int k = gy + 8; k < NS; k += 8)
 #pragma unroll
       for (int u = 0; u < K; u++) insert(s_k[k][u][bx]);
 #pragma unroll
-    for (int t = 0; t < K; t++) s_k[gy][t][bx] = mine[t];      // (slices 0-3 are read by nobody but slice 0, below)
+    for (int t = 0; t < K; t++) s_k[gy][t][bx] = mine[t];      // (slices 0-7 are read by nobody but slice 0, below)
   }
   __syncthreads();
   if (gy == 0) {
-    for (int k = 1; k < 4; k++)
+    for (int k = 1; k < 8; k++)
 #pragma unroll
       for (int u = 0; u < K; u++) insert(s_k[k][u][bx]);
     const float mk = mine[K - 1];
@@ -220,12 +222,12 @@ __global__ __launch_bounds__(1024) void k_topk_select(CbView cb, int64_t count, 
   const float thr = s_thr[bx];
   uint32_t n = 0;
   if (valid)
-    for (int64_t g = gy; g < cb.ngroups; g += 32) n += wmin[g * bpad + b] <= thr ? 1u : 0u;
+    for (int64_t g = gy; g < cb.ngroups; g += NS) n += wmin[g * bpad + b] <= thr ? 1u : 0u;
   s_n[gy][bx] = n;
   __syncthreads();
   if (gy == 0 && valid) {
     uint32_t total = 0;
-    for (int k = 0; k < 32; k++) total += s_n[k][bx];
+    for (int k = 0; k < NS; k++) total += s_n[k][bx];
     const uint32_t start = atomicAdd(counter, total);
     if (start + total > cap) atomicMax(counter + 1, 1u);
     span[b].start = start; span[b].n = total;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(1024) void k_topk_select(CbView cb, int64_t count, 
   if (!valid || s_start[bx] + s_total[bx] > cap) return;
   uint32_t at = s_start[bx];
   for (int k = 0; k < gy; k++) at += s_n[k][bx];
-  for (int64_t g = gy; g < cb.ngroups; g += 32) {
+  for (int64_t g = gy; g < cb.ngroups; g += NS) {
     if (wmin[g * bpad + b] <= thr) {
       const uint32_t p = at++;
       pairs[p] = make_uint2(static_cast<uint32_t>(b), static_cast<uint32_t>(g));
