@@ -1148,7 +1148,13 @@ __global__ __launch_bounds__(256) void k_dist_l2(CbView cb, int d8, const uint4 
 // of eight K-steps in flight.  With 16 384-vector batches a group has four or five tiles: the operand-A traffic of
 // k_dist_l2 (each tile re-reading the group's 128 KiB through L2) was most of that kernel's time.  Same products in the
 // same order as k_dist_l2.
-constexpr int L2_WAVES = 8;            // waves of a k_dist_l2_lds workgroup (one workgroup per CU: its LDS holds a group's tiles)
+#ifndef L2_WAVES_V
+#define L2_WAVES_V 8
+#endif
+#ifndef L2_DEPTH_V
+#define L2_DEPTH_V 2       // K-steps of operand B per register block (two blocks in rotation).  Round 3, us per 32768-vector
+#endif                   // launch along the configs[3] schedule: depth 8 (round 2) 546 ... 91, 4: 498 ... 80, 2: 444 ... 73, 1: 453 ... 79
+constexpr int L2_WAVES = L2_WAVES_V;   // waves of a k_dist_l2_lds workgroup (one workgroup per CU: its LDS holds a group's tiles)
 __global__ __launch_bounds__(64 * L2_WAVES, 1) void k_dist_l2_lds(CbView cb, int d8, const uint4 *__restrict__ chi, const uint4 *__restrict__ clo,
                                                         const uint4 *__restrict__ xhi, const uint4 *__restrict__ xlo,
                                                         const float *__restrict__ cn, const float *__restrict__ tau, int64_t bpad,
@@ -1175,7 +1181,7 @@ __global__ __launch_bounds__(64 * L2_WAVES, 1) void k_dist_l2_lds(CbView cb, int
   __syncthreads();
   const uint4 *sah = s_l2a, *sal = s_l2a + d8 * 64;
   const int nks = d8 / 2;                                  // K-step ks uses k-blocks 2 ks + half
-  constexpr int D = 8;
+  constexpr int D = L2_DEPTH_V;
   for (int tile = blockIdx.y * L2_WAVES + wave; tile < ntiles; tile += L2_WAVES * gridDim.y) {
     const int slot = tile * 32 + l31;
     const bool valid = slot < n;
