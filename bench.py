@@ -433,8 +433,9 @@ def bench_som(a):
                              "frac": alg / avg_s / 1e12 / PEAK_BF16_TFLOPS})
                 if two_level:
                     base["note"] = ("level 1 of the two-level pre-filter: ||c||^2 - 2<c_hi, x_hi> for every (code, vector) pair, one "
-                                    "v_mfma_f32_32x32x16_bf16 per K-step (executed = ALGORITHMIC 2*N*d flop per vector) over the dense "
-                                    "bf16 peak; 8 such MFMAs back to back take 146 ns on this part (tools/micro/mfma_indep.hip -DBF16): "
+                                    "bf16 MFMA per K-step (k_dist_mfma_bf16_l1r: v_mfma_f32_16x16x32_bf16; executed = ALGORITHMIC 2*N*d flop "
+                                    "per vector) over the dense bf16 peak; 8 32x32x16 MFMAs back to back take 146 ns on this part "
+                                    "(tools/micro/mfma_indep.hip -DBF16): "
                                     "1.84 Pflop/s is what the instruction sustains; the level-2 three-product GEMM on the survivors and "
                                     "the exact re-rank are separate kernels (k_dist_l2, k_rerank_*)")
                     base["frac_of_sustained_mfma_rate"] = alg / avg_s / 1e12 / 1840.0
