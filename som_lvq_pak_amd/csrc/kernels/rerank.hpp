@@ -285,7 +285,10 @@ __global__ __launch_bounds__(64) void k_topk_pairs_bygroup(CbView cb, const floa
   const uint32_t nwork = *wcount < wcap ? *wcount : wcap;
   const int lane = threadIdx.x & 63;
   const int64_t first0 = first % n_rows;
-  constexpr int U = 8;                                   // tile chunks per register buffer (two buffers, as in K3's row stream)
+#ifndef TOPK_U
+#define TOPK_U 4            // (configs[4] shape, k_rerank per batch: 2: 210 us, 4: 178, 8: 188, 16: 379)
+#endif
+  constexpr int U = TOPK_U;                              // tile chunks per register buffer (two buffers, as in K3's row stream)
   for (uint32_t w = blockIdx.x; w < nwork; w += gridDim.x) {
     const int64_t g = work[w].x;
     const uint32_t base = work[w].y;
