@@ -21,7 +21,7 @@ init = E.randinit_from_bbox(lo, hi, cnt, xdim, ydim, 7)
 cb = E.Codebook(eng, init, E.TOPOL_HEXA, E.NEIGH_BUBBLE, xdim, ydim)
 N = 16384
 ref = {}
-for u in (8, 16, 24):
+for u in [int(v) for v in os.environ.get("ONLINE_U_LIST", "2,4,8,16").split(",")]:
     os.environ["SOMHIP_ONLINE_U"] = str(u)
     for tag, it0 in (("head (radius 128)", 0), ("tail (radius 2)", 9_900_000)):
         cb.upload(init)
